@@ -1,0 +1,466 @@
+// hispmv_abi.cpp -- the C ABI of libhispmv.so (include/hispmv.h): context, matrix handles,
+// arena accounting, HBM upload and launches.  MI355X counterpart of the reference's
+// FpgaHandle (pyhispmv/src/fpga_handle.cpp:40-388), which owns the XRT device, the
+// per-channel matrix arena and the kernel run object.  Host-side HIP runtime calls only;
+// the kernels live in hispmv_kernels.hip, the preprocessor in hispmv_prep.cpp.
+#include "../../include/hispmv.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hispmv_kernels.h"
+#include "hispmv_prep.h"
+
+#define HISPMV_API extern "C" __attribute__((visibility("default")))
+
+using namespace hispmv;
+
+namespace {
+
+struct Matrix {
+    bool dense = false;
+    int32_t rows = 0, cols = 0;
+    int64_t nnz = 0;
+    double prep_seconds = 0;
+    int64_t device_bytes = 0;
+    bool loaded = false;
+    // host side (released after upload)
+    SliceStream st;
+    std::vector<FixEntry> fix_short, fix_long;
+    std::vector<float> dense_host;
+    int64_t n_slices = 0, n_elems = 0, n_split = 0;
+    // device side
+    SpmvDeviceMatrix dev;
+    float* d_dense = nullptr;
+    std::vector<void*> allocs;
+};
+
+}  // namespace
+
+struct hispmv_ctx {
+    int device = 0;
+    int num_ch_A = 0, num_ch_B = 0, num_ch_C = 0, urams_per_pe = 0, fp_acc_latency = 0;
+    bool dense_overlay = false, pre_accumulator = false, row_dist_net = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = -1.0f;
+    std::mutex mu;
+    std::string err;
+    std::vector<std::unique_ptr<Matrix>> mats;
+    int selected = -1;
+    int64_t arena_budget = 0, arena_used = 0;
+    float *d_x = nullptr, *d_bias = nullptr, *d_y = nullptr;
+    int64_t cap_x = 0, cap_bias = 0, cap_y = 0;
+};
+
+struct hispmv_prep {
+    Csr csr;
+    SliceStream st;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+thread_local std::string g_prep_err;
+
+int fail(hispmv_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+int hip_fail(hispmv_ctx* c, hipError_t e, const char* what) {
+    return fail(c, HISPMV_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(c, call)                                        \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail((c), e_, #call);  \
+    } while (0)
+
+int64_t sparse_device_bytes(const SliceStream& st) {
+    return (int64_t)st.words.size() * 8 + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
+           (int64_t)st.n_slices * 4;
+}
+
+void free_matrix_device(Matrix& m) {
+    for (void* p : m.allocs) (void)hipFree(p);
+    m.allocs.clear();
+    m.dev = SpmvDeviceMatrix{};
+    m.d_dense = nullptr;
+    m.loaded = false;
+}
+
+int ensure_vec(hispmv_ctx* c, float** p, int64_t* cap, int64_t n) {
+    if (n <= *cap) return HISPMV_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const int64_t want = std::max<int64_t>(n, 1024);
+    HIP_TRY(c, hipMalloc((void**)p, (size_t)want * sizeof(float)));
+    *cap = want;
+    return HISPMV_OK;
+}
+
+// Registers a prepared sparse matrix with the context (capacity check = the reference's
+// "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).
+int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
+    auto t0 = std::chrono::steady_clock::now();
+    auto m = std::make_unique<Matrix>();
+    m->rows = csr.rows; m->cols = csr.cols; m->nnz = csr.nnz();
+    m->st = build_stream(csr);
+    csr = Csr{};
+    for (const FixEntry& f : m->st.fix) (f.len <= kFixShortMax ? m->fix_short : m->fix_long).push_back(f);
+    m->n_slices = m->st.n_slices; m->n_elems = m->st.n_elems; m->n_split = (int64_t)m->st.fix.size();
+    m->device_bytes = sparse_device_bytes(m->st);
+    m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
+    c->arena_used += m->device_bytes;
+    c->mats.push_back(std::move(m));
+    return (int)c->mats.size() - 1;
+}
+
+template <class T>
+int upload(hispmv_ctx* c, Matrix& m, const T* host, size_t count, const T** dev_out) {
+    *dev_out = nullptr;
+    if (count == 0) return HISPMV_OK;
+    void* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, count * sizeof(T)));
+    m.allocs.push_back(d);
+    HIP_TRY(c, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dev_out = (const T*)d;
+    return HISPMV_OK;
+}
+
+int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
+                  float alpha, float beta, hipStream_t s) {
+    hipError_t e = m.dense ? launch_gemv(m.d_dense, m.rows, m.cols, d_x, d_bias, d_y, alpha, beta, s)
+                           : launch_spmv(m.dev, d_x, d_bias, d_y, alpha, beta, s);
+    if (e != hipSuccess) return hip_fail(c, e, m.dense ? "launch_gemv" : "launch_spmv");
+    return HISPMV_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+HISPMV_API const char* hispmv_version(void) { return "hispmv-amd 0.1.0 gfx950"; }
+
+HISPMV_API const char* hispmv_last_error(const hispmv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int device_id, int a, int b, int cc,
+                             int urams, int fp_acc_latency, int dense, int pre_acc, int row_dist) {
+    if (!out) return fail(nullptr, HISPMV_EINVAL, "out is NULL");
+    *out = nullptr;
+    // same argument checks as fpga_handle.cpp:51-52,70-71
+    if (device_id < 0) return fail(nullptr, HISPMV_EINVAL, "Device ID must be a non-negative integer.");
+    if (!xclbin_path || !*xclbin_path) return fail(nullptr, HISPMV_EINVAL, "XCLBIN path is empty.");
+    if (a <= 0 || b <= 0 || cc <= 0) return fail(nullptr, HISPMV_EINVAL, "channel counts must be positive");
+    if ((a * 8) % (cc * 16) != 0)   // spmv-helper.cpp:15
+        return fail(nullptr, HISPMV_EINVAL, "Number of PEs should be an integer multiple of Number of FP32 elements in output vector");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, HISPMV_EDEVICE, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device_id >= ndev) return fail(nullptr, HISPMV_EDEVICE, "device_id out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HISPMV_EDEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+
+    auto c = std::make_unique<hispmv_ctx>();
+    c->device = device_id;
+    c->num_ch_A = a; c->num_ch_B = b; c->num_ch_C = cc; c->urams_per_pe = urams; c->fp_acc_latency = fp_acc_latency;
+    c->dense_overlay = dense != 0; c->pre_accumulator = pre_acc != 0; c->row_dist_net = row_dist != 0;
+    c->arena_budget = (int64_t)a * 256 * 1024 * 1024;      // fpga_handle.h:12, one 256 MiB bank per A channel
+    if (const char* env = std::getenv("HISPMV_ARENA_BYTES")) { long long v = std::atoll(env); if (v > 0) c->arena_budget = v; }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(nullptr, e, "hipStreamCreate");
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return hip_fail(nullptr, e, "hipEventCreate");
+    *out = c.release();
+    return HISPMV_OK;
+}
+
+HISPMV_API void hispmv_destroy(hispmv_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& m : c->mats) free_matrix_device(*m);
+    if (c->d_x) (void)hipFree(c->d_x);
+    if (c->d_bias) (void)hipFree(c->d_bias);
+    if (c->d_y) (void)hipFree(c->d_y);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+HISPMV_API int hispmv_set_arena_bytes(hispmv_ctx* c, int64_t bytes) {
+    if (!c || bytes < 0) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->arena_budget = bytes;
+    return HISPMV_OK;
+}
+HISPMV_API int64_t hispmv_arena_bytes_used(const hispmv_ctx* c) { return c ? c->arena_used : 0; }
+
+HISPMV_API int hispmv_create_sparse_handle(hispmv_ctx* c, const int32_t* r, const int32_t* cl, const float* v,
+                                           int64_t nnz, int32_t rows, int32_t cols) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rows <= 0 || cols <= 0 || nnz < 0 || (nnz > 0 && (!r || !cl || !v))) return fail(c, HISPMV_EINVAL, "bad sparse matrix arguments");
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        Csr csr = coo_to_csr(rows, cols, nnz, r, cl, v);
+        double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return add_sparse(c, std::move(csr), t);
+    } catch (const std::out_of_range& ex) { return fail(c, HISPMV_EINVAL, ex.what());
+    } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory");
+    } catch (const std::exception& ex) { return fail(c, HISPMV_EINVAL, ex.what()); }
+}
+
+HISPMV_API int hispmv_create_sparse_handle_from_mtx(hispmv_ctx* c, const char* path, int flavor) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!path || (flavor != 0 && flavor != 1)) return fail(c, HISPMV_EINVAL, "bad arguments");
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        Coo coo = read_mtx(path, (MtxFlavor)flavor);
+        auto t1 = std::chrono::steady_clock::now();   // like the reference, file parsing is not "Pre-processing Time"
+        Csr csr = coo_to_csr(coo.rows, coo.cols, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), coo.v.data());
+        (void)t0;
+        double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        return add_sparse(c, std::move(csr), t);
+    } catch (const std::runtime_error& ex) { return fail(c, HISPMV_EIO, ex.what());
+    } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory");
+    } catch (const std::exception& ex) { return fail(c, HISPMV_EINVAL, ex.what()); }
+}
+
+HISPMV_API int hispmv_create_sparse_handle_from_csr(hispmv_ctx* c, const int32_t* rp, const int32_t* ci, const float* va,
+                                                    int32_t rows, int32_t cols) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rows <= 0 || cols <= 0 || !rp) return fail(c, HISPMV_EINVAL, "bad CSR arguments");
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        Csr csr;
+        csr.rows = rows; csr.cols = cols;
+        csr.row_ptr.resize((size_t)rows + 1);
+        for (int32_t i = 0; i <= rows; ++i) csr.row_ptr[i] = rp[i];
+        const int64_t nnz = rp[rows];
+        if (rp[0] != 0 || nnz < 0) return fail(c, HISPMV_EINVAL, "row_ptr must start at 0");
+        for (int32_t i = 0; i < rows; ++i) if (rp[i + 1] < rp[i]) return fail(c, HISPMV_EINVAL, "row_ptr must be non-decreasing");
+        csr.col.assign(ci, ci + nnz); csr.val.assign(va, va + nnz);
+        for (int64_t k = 0; k < nnz; ++k) if (ci[k] < 0 || ci[k] >= cols) return fail(c, HISPMV_EINVAL, "CSR column outside matrix");
+        double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return add_sparse(c, std::move(csr), t);
+    } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory");
+    } catch (const std::exception& ex) { return fail(c, HISPMV_EINVAL, ex.what()); }
+}
+
+HISPMV_API int hispmv_create_dense_handle(hispmv_ctx* c, const float* vals, int32_t rows, int32_t cols) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->dense_overlay)   // assert at spmv-helper.cpp:718
+        return fail(c, HISPMV_ENOTDENSE, "Hardware is not built with Dense Overlay, cannot support dense workload");
+    if (rows <= 0 || cols <= 0 || !vals) return fail(c, HISPMV_EINVAL, "bad dense matrix arguments");
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        auto m = std::make_unique<Matrix>();
+        m->dense = true; m->rows = rows; m->cols = cols; m->nnz = (int64_t)rows * cols;   // spmv-helper.cpp:722
+        m->device_bytes = m->nnz * 4;
+        if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
+        m->dense_host.assign(vals, vals + m->nnz);
+        m->prep_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        c->arena_used += m->device_bytes;
+        c->mats.push_back(std::move(m));
+        return (int)c->mats.size() - 1;
+    } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory"); }
+}
+
+HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (auto& mp : c->mats) {
+        Matrix& m = *mp;
+        if (m.loaded) continue;
+        int rc;
+        if (m.dense) {
+            const float* d = nullptr;
+            if ((rc = upload(c, m, m.dense_host.data(), m.dense_host.size(), &d)) != HISPMV_OK) return rc;
+            m.d_dense = const_cast<float*>(d);
+        } else {
+            const uint64_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
+            if ((rc = upload(c, m, m.st.words.data(), m.st.words.size(), &dw)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, m.st.hdr.data(), m.st.hdr.size(), &dh)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, m.fix_short.data(), m.fix_short.size(), &fs)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, m.fix_long.data(), m.fix_long.size(), &fl)) != HISPMV_OK) return rc;
+            void* carry = nullptr;
+            HIP_TRY(c, hipMalloc(&carry, (size_t)std::max<int64_t>(m.n_slices, 1) * sizeof(float)));
+            m.allocs.push_back(carry);
+            HIP_TRY(c, hipMemsetAsync(carry, 0, (size_t)std::max<int64_t>(m.n_slices, 1) * sizeof(float), c->stream));
+            m.dev.words = dw; m.dev.hdr = (const int4*)dh;
+            m.dev.fix_short = (const int4*)fs; m.dev.fix_long = (const int4*)fl;
+            m.dev.carry = (float*)carry;
+            m.dev.n_slices = m.n_slices;
+            m.dev.n_fix_short = (int32_t)m.fix_short.size(); m.dev.n_fix_long = (int32_t)m.fix_long.size();
+            m.dev.rows = m.rows; m.dev.cols = m.cols;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // host copies are no longer needed
+        m.st = SliceStream{}; m.fix_short = {}; m.fix_long = {}; m.dense_host = {};
+        m.loaded = true;
+    }
+    return HISPMV_OK;
+}
+
+HISPMV_API int hispmv_select_matrix(hispmv_ctx* c, uint32_t idx) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (idx >= c->mats.size()) return fail(c, HISPMV_EINVAL, "Matrix idx out of range");   // fpga_handle.cpp:267-270
+    c->selected = (int)idx;
+    return HISPMV_OK;
+}
+
+static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t num_vecs, const float* bias,
+                            float* y, float alpha, float beta) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_vec(c, &c->d_x, &c->cap_x, (int64_t)m.cols * num_vecs)) != HISPMV_OK) return rc;
+    if ((rc = ensure_vec(c, &c->d_bias, &c->cap_bias, m.rows)) != HISPMV_OK) return rc;
+    if ((rc = ensure_vec(c, &c->d_y, &c->cap_y, (int64_t)m.rows * num_vecs)) != HISPMV_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_x, x, (size_t)m.cols * num_vecs * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (beta != 0.0f)
+        HIP_TRY(c, hipMemcpyAsync(c->d_bias, bias, (size_t)m.rows * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (int64_t k = 0; k < num_vecs; ++k)
+        if ((rc = launch_matrix(c, m, c->d_x + k * m.cols, c->d_bias, c->d_y + k * m.rows, alpha, beta, c->stream)) != HISPMV_OK) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(y, c->d_y, (size_t)m.rows * num_vecs * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1) != hipSuccess) c->last_ms = -1.0f;
+    return HISPMV_OK;
+}
+
+HISPMV_API int hispmv_run_kernel(hispmv_ctx* c, const float* x, const float* bias, float* y, float alpha, float beta) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->selected < 0) return fail(c, HISPMV_ESTATE, "Run Kernel called before selecting a matrix");   // assert :292
+    Matrix& m = *c->mats[c->selected];
+    if (!m.loaded) return fail(c, HISPMV_ESTATE, "run_kernel called before load_matrices");
+    if (!x || !y || (beta != 0.0f && !bias)) return fail(c, HISPMV_EINVAL, "NULL vector");
+    return run_host_vectors(c, m, x, 1, bias, y, alpha, beta);
+}
+
+HISPMV_API int hispmv_linear(hispmv_ctx* c, int idx, const float* x, int64_t x_len, const float* bias, float* y_out) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (idx < 0 || idx >= (int)c->mats.size()) return fail(c, HISPMV_EINVAL, "Matrix idx out of range");
+    Matrix& m = *c->mats[idx];
+    if (!m.loaded) return fail(c, HISPMV_ESTATE, "linear called before load_matrices");
+    if (!x || !bias || !y_out) return fail(c, HISPMV_EINVAL, "NULL vector");
+    const int64_t num_vecs = x_len / m.cols;   // fpga_handle.cpp:336
+    if (num_vecs <= 0) return fail(c, HISPMV_EINVAL, "x shorter than one input vector");
+    return run_host_vectors(c, m, x, num_vecs, bias, y_out, 1.0f, 1.0f);   // alpha = beta = 1, :351-352
+}
+
+HISPMV_API int hispmv_spmv_device(hispmv_ctx* c, int idx, const float* d_x, const float* d_bias, float* d_y,
+                                  float alpha, float beta, void* stream) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (idx < 0 || idx >= (int)c->mats.size()) return fail(c, HISPMV_EINVAL, "Matrix idx out of range");
+    Matrix& m = *c->mats[idx];
+    if (!m.loaded) return fail(c, HISPMV_ESTATE, "spmv_device called before load_matrices");
+    if (!d_x || !d_y || (beta != 0.0f && !d_bias)) return fail(c, HISPMV_EINVAL, "NULL device vector");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, stream ? (hipStream_t)stream : c->stream);
+}
+
+HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
+    if (!c) return HISPMV_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HISPMV_OK;
+}
+
+HISPMV_API float hispmv_last_kernel_ms(hispmv_ctx* c) { return c ? c->last_ms : -1.0f; }
+
+HISPMV_API float hispmv_time_device(hispmv_ctx* c, int idx, const float* d_x, const float* d_bias, float* d_y,
+                                    float alpha, float beta, int reps) {
+    if (!c || reps <= 0) return -1.0f;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (idx < 0 || idx >= (int)c->mats.size() || !c->mats[idx]->loaded) { c->err = "bad matrix for time_device"; return -1.0f; }
+    Matrix& m = *c->mats[idx];
+    if (hipSetDevice(c->device) != hipSuccess) return -1.0f;
+    if (hipEventRecord(c->ev0, c->stream) != hipSuccess) return -1.0f;
+    for (int i = 0; i < reps; ++i)
+        if (launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, c->stream) != HISPMV_OK) return -1.0f;
+    if (hipEventRecord(c->ev1, c->stream) != hipSuccess) return -1.0f;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+    return ms / reps;
+}
+
+HISPMV_API int hispmv_num_matrices(const hispmv_ctx* c) { return c ? (int)c->mats.size() : 0; }
+
+HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matrix_info* out) {
+    if (!c || !out || idx < 0 || idx >= (int)c->mats.size()) return HISPMV_EINVAL;
+    const Matrix& m = *c->mats[idx];
+    out->rows = m.rows; out->cols = m.cols; out->nnz = m.nnz; out->is_dense = m.dense; out->loaded = m.loaded;
+    out->n_slices = m.n_slices; out->n_elems = m.n_elems; out->n_split_rows = m.n_split;
+    out->device_bytes = m.device_bytes; out->prep_seconds = m.prep_seconds;
+    return HISPMV_OK;
+}
+
+// ---- host-only preprocessor access ---------------------------------------------------------------
+HISPMV_API const char* hispmv_prep_last_error(void) { return g_prep_err.c_str(); }
+
+HISPMV_API int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* r, const int32_t* cl, const float* v,
+                                    int64_t nnz, int32_t rows, int32_t cols) {
+    if (!out) return HISPMV_EINVAL;
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || nnz < 0) { g_prep_err = "bad sparse matrix arguments"; return HISPMV_EINVAL; }
+    try {
+        auto p = std::make_unique<hispmv_prep>();
+        p->csr = coo_to_csr(rows, cols, nnz, r, cl, v);
+        p->st = build_stream(p->csr);
+        *out = p.release();
+        return HISPMV_OK;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
+
+HISPMV_API int hispmv_prep_from_mtx(hispmv_prep** out, const char* path, int flavor) {
+    if (!out) return HISPMV_EINVAL;
+    *out = nullptr;
+    if (!path || (flavor != 0 && flavor != 1)) { g_prep_err = "bad arguments"; return HISPMV_EINVAL; }
+    try {
+        Coo coo = read_mtx(path, (MtxFlavor)flavor);
+        auto p = std::make_unique<hispmv_prep>();
+        p->csr = coo_to_csr(coo.rows, coo.cols, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), coo.v.data());
+        p->st = build_stream(p->csr);
+        *out = p.release();
+        return HISPMV_OK;
+    } catch (const std::runtime_error& ex) { g_prep_err = ex.what(); return HISPMV_EIO;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
+
+HISPMV_API void hispmv_prep_free(hispmv_prep* p) { delete p; }
+
+HISPMV_API int hispmv_prep_dims(const hispmv_prep* p, int64_t d[8]) {
+    if (!p || !d) return HISPMV_EINVAL;
+    d[0] = p->st.rows; d[1] = p->st.cols; d[2] = p->st.nnz; d[3] = p->st.n_elems; d[4] = p->st.n_slices;
+    d[5] = kSliceElems; d[6] = (int64_t)p->st.fix.size(); d[7] = p->st.bytes();
+    return HISPMV_OK;
+}
+HISPMV_API const int64_t* hispmv_prep_csr_row_ptr(const hispmv_prep* p) { return p->csr.row_ptr.data(); }
+HISPMV_API const int32_t* hispmv_prep_csr_col(const hispmv_prep* p) { return p->csr.col.data(); }
+HISPMV_API const float* hispmv_prep_csr_val(const hispmv_prep* p) { return p->csr.val.data(); }
+HISPMV_API const uint64_t* hispmv_prep_words(const hispmv_prep* p) { return p->st.words.data(); }
+HISPMV_API const int32_t* hispmv_prep_slice_hdr(const hispmv_prep* p) { return (const int32_t*)p->st.hdr.data(); }
+HISPMV_API const int32_t* hispmv_prep_fix(const hispmv_prep* p) { return (const int32_t*)p->st.fix.data(); }

@@ -1,0 +1,216 @@
+// hispmv_prep.cpp -- see hispmv_prep.h.  Host-only, OpenMP.
+#include "hispmv_prep.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+
+namespace hispmv {
+
+// ---------------------------------------------------------------------------
+// MatrixMarket
+// ---------------------------------------------------------------------------
+static std::string lower(std::string s) {
+    for (auto& ch : s) ch = (char)std::tolower((unsigned char)ch);
+    return s;
+}
+
+Coo read_mtx(const std::string& path, MtxFlavor flavor) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Error: Unable to open file " + path);
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::string buf((size_t)std::max(0L, sz), '\0');
+    if (sz > 0 && std::fread(&buf[0], 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw std::runtime_error("Error: short read on " + path); }
+    std::fclose(f);
+
+    const char* p = buf.c_str();
+    const char* end = p + buf.size();
+    auto next_line = [&](const char*& b, const char*& e) -> bool {
+        if (p >= end) return false;
+        b = p;
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+        e = nl ? nl : end;
+        p = nl ? nl + 1 : end;
+        return true;
+    };
+    const char *lb, *le;
+    if (!next_line(lb, le)) throw std::runtime_error("Error: Not a valid Matrix Market file.");
+    std::string tok[5];
+    {
+        std::string line(lb, le);
+        size_t pos = 0;
+        for (int i = 0; i < 5; i++) {
+            while (pos < line.size() && std::isspace((unsigned char)line[pos])) pos++;
+            size_t st = pos;
+            while (pos < line.size() && !std::isspace((unsigned char)line[pos])) pos++;
+            tok[i] = line.substr(st, pos - st);
+        }
+    }
+    if (tok[0] != "%%MatrixMarket" || lower(tok[1]) != "matrix") throw std::runtime_error("Error: Not a valid Matrix Market file.");
+    const std::string fmt = lower(tok[2]), dt = lower(tok[3]), sym = lower(tok[4]);
+    if (fmt != "coordinate") throw std::runtime_error("Error: Only sparse matrices in 'coordinate' format are supported.");
+    if (dt != "real" && dt != "integer" && dt != "pattern") throw std::runtime_error("Error: Unsupported data type.");
+    if (sym != "general" && sym != "symmetric" && sym != "skew-symmetric")
+        throw std::runtime_error("Error: Unsupported symmetry type. Only 'general', 'symmetric', and 'skew-symmetric' are supported.");
+    const bool pattern = dt == "pattern";
+    const bool mirror_sym = sym == "symmetric";
+    const bool mirror_skew = (sym == "skew-symmetric") && flavor == kFlavorCommon;   // cpu/ does not mirror skew
+
+    long M = 0, N = 0, nz = 0;
+    while (next_line(lb, le)) {
+        if (lb < le && *lb == '%') continue;
+        std::string line(lb, le);
+        if (std::sscanf(line.c_str(), "%ld %ld %ld", &M, &N, &nz) == 3) break;
+    }
+    if (M <= 0 || N <= 0 || nz < 0 || M > INT32_MAX || N > INT32_MAX) throw std::runtime_error("Error: bad size line in " + path);
+
+    Coo out;
+    out.rows = (int32_t)M; out.cols = (int32_t)N;
+    const size_t cap = (size_t)nz * ((mirror_sym || mirror_skew) ? 2 : 1);
+    out.r.reserve(cap); out.c.reserve(cap); out.v.reserve(cap);
+    const char* q = p;
+    for (long i = 0; i < nz && q < end; ++i) {
+        char* e1;
+        long r = std::strtol(q, &e1, 10);
+        if (e1 == q) break;
+        q = e1;
+        long c = std::strtol(q, &e1, 10);
+        if (e1 == q) break;
+        q = e1;
+        float v = 1.0f;
+        if (!pattern) { v = std::strtof(q, &e1); if (e1 == q) break; q = e1; }
+        while (q < end && *q != '\n') q++;   // ignore the rest of the line
+        uint32_t bits; std::memcpy(&bits, &v, 4);
+        const bool drop = (flavor == kFlavorCommon) ? (v == 0.0f) : (bits == 0u);
+        if (drop) continue;
+        if (r < 1 || c < 1 || r > M || c > N) throw std::runtime_error("Error: entry out of range in " + path);
+        out.r.push_back((int32_t)(r - 1)); out.c.push_back((int32_t)(c - 1)); out.v.push_back(v);
+        if (r != c) {
+            if (mirror_sym) { out.r.push_back((int32_t)(c - 1)); out.c.push_back((int32_t)(r - 1)); out.v.push_back(v); }
+            else if (mirror_skew) { out.r.push_back((int32_t)(c - 1)); out.c.push_back((int32_t)(r - 1)); out.v.push_back(-v); }
+        }
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// COO -> CSR
+// ---------------------------------------------------------------------------
+Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const int32_t* c, const float* v) {
+    if (rows < 0 || cols < 0 || nnz < 0) throw std::out_of_range("negative dimension");
+    Csr m;
+    m.rows = rows; m.cols = cols;
+    m.row_ptr.assign((size_t)rows + 1, 0);
+    m.col.resize((size_t)nnz);
+    m.val.resize((size_t)nnz);
+
+    bool bad = false;
+#pragma omp parallel for schedule(static) reduction(|| : bad)
+    for (int64_t i = 0; i < nnz; ++i)
+        bad = bad || (r[i] < 0 || r[i] >= rows || c[i] < 0 || c[i] >= cols);
+    if (bad) throw std::out_of_range("COO index outside matrix dimensions");
+
+    for (int64_t i = 0; i < nnz; ++i) m.row_ptr[(size_t)r[i] + 1]++;
+    for (int32_t i = 0; i < rows; ++i) m.row_ptr[(size_t)i + 1] += m.row_ptr[i];
+    {
+        std::vector<int64_t> cur(m.row_ptr.begin(), m.row_ptr.end() - 1);
+        for (int64_t i = 0; i < nnz; ++i) {
+            int64_t k = cur[r[i]]++;
+            m.col[k] = c[i];
+            m.val[k] = v[i];
+        }
+    }
+    // stable sort by column inside each row (rows already ascending are skipped)
+#pragma omp parallel
+    {
+        std::vector<std::pair<int32_t, float>> tmp;
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t i = 0; i < rows; ++i) {
+            const int64_t s = m.row_ptr[i], e = m.row_ptr[(size_t)i + 1];
+            if (e - s < 2) continue;
+            bool sorted = true;
+            for (int64_t k = s + 1; k < e; ++k) if (m.col[k] < m.col[k - 1]) { sorted = false; break; }
+            if (sorted) continue;
+            tmp.resize((size_t)(e - s));
+            for (int64_t k = s; k < e; ++k) tmp[k - s] = {m.col[k], m.val[k]};
+            std::stable_sort(tmp.begin(), tmp.end(),
+                             [](const std::pair<int32_t, float>& a, const std::pair<int32_t, float>& b) { return a.first < b.first; });
+            for (int64_t k = s; k < e; ++k) { m.col[k] = tmp[k - s].first; m.val[k] = tmp[k - s].second; }
+        }
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------
+// CSR -> slice stream
+// ---------------------------------------------------------------------------
+SliceStream build_stream(const Csr& m) {
+    SliceStream st;
+    st.rows = m.rows; st.cols = m.cols; st.nnz = m.nnz();
+    const int32_t R = m.rows;
+    const int64_t S = kSliceElems;
+    // element offset of each row: every row owns >= 1 element (empty rows get one
+    // zero-valued filler so that "one row end per row" holds and row ids need no list)
+    std::vector<int64_t> eoff((size_t)R + 1, 0);
+    for (int32_t i = 0; i < R; ++i) {
+        const int64_t len = m.row_ptr[(size_t)i + 1] - m.row_ptr[i];
+        eoff[(size_t)i + 1] = eoff[i] + (len > 0 ? len : 1);
+    }
+    st.n_elems = eoff[R];
+    st.n_slices = (st.n_elems + S - 1) / S;
+    st.words.assign((size_t)(st.n_slices * S), pack_elem(0.0f, 0, false));
+    st.hdr.assign((size_t)st.n_slices, SliceHdr{0, 0, 0, 1});
+
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < R; ++i) {
+        const int64_t s = m.row_ptr[i], e = m.row_ptr[(size_t)i + 1];
+        uint64_t* w = st.words.data() + eoff[i];
+        if (e == s) { w[0] = pack_elem(0.0f, 0, true); continue; }
+        for (int64_t k = s; k < e; ++k) w[k - s] = pack_elem(m.val[k], m.col[k], k + 1 == e);
+    }
+
+    std::vector<uint8_t> has_fix((size_t)st.n_slices, 0);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t sl = 0; sl < st.n_slices; ++sl) {
+        const int64_t b = sl * S, e = std::min(b + S, st.n_elems);
+        // rows that END before element b
+        const int64_t rb = std::upper_bound(eoff.begin() + 1, eoff.end(), b) - (eoff.begin() + 1);
+        const int64_t rb_next = std::upper_bound(eoff.begin() + 1, eoff.end(), b + S) - (eoff.begin() + 1);
+        SliceHdr h{(int32_t)rb, 0, 0, 1};
+        if (rb < R && eoff[rb] < b && rb_next > rb) {    // first row ending here began earlier
+            h.chain_len = (int32_t)(sl - eoff[rb] / S);
+            has_fix[sl] = 1;
+        }
+        // column window over the real elements; fillers/padding take the window's base
+        int32_t cmin = INT32_MAX, cmax = -1;
+        for (int64_t r = rb; r < R && eoff[r] < e; ++r) {
+            const int64_t len = m.row_ptr[(size_t)r + 1] - m.row_ptr[r];
+            if (len == 0) continue;
+            const int64_t k0 = m.row_ptr[r] + std::max<int64_t>(0, b - eoff[r]);
+            const int64_t k1 = m.row_ptr[r] + std::min<int64_t>(len, e - eoff[r]);
+            if (k0 < k1) { cmin = std::min(cmin, m.col[k0]); cmax = std::max(cmax, m.col[k1 - 1]); }
+        }
+        if (cmax < 0) { cmin = 0; cmax = 0; }
+        h.x_base = cmin; h.x_span = cmax - cmin + 1;
+        if (cmin != 0) {
+            for (int64_t r = rb; r < R && eoff[r] < e; ++r)
+                if (m.row_ptr[(size_t)r + 1] == m.row_ptr[r] && eoff[r] >= b) st.words[eoff[r]] = pack_elem(0.0f, cmin, true);
+            for (int64_t k = e; k < b + S; ++k) st.words[k] = pack_elem(0.0f, cmin, false);
+        }
+        st.hdr[sl] = h;
+    }
+    for (int64_t sl = 0; sl < st.n_slices; ++sl)
+        if (has_fix[sl]) {
+            const SliceHdr& h = st.hdr[sl];
+            st.fix.push_back(FixEntry{h.row_base, (int32_t)(sl - h.chain_len), h.chain_len, 0});
+        }
+    return st;
+}
+
+}  // namespace hispmv

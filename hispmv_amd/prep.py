@@ -1,0 +1,71 @@
+"""Host-only access to the preprocessor (COO / MatrixMarket -> CSR -> slice stream) through the
+C ABI's ``hispmv_prep_*`` entry points.  No device is needed; tests use it to compare the CSR
+indices and the packed stream against the oracle on a CPU-only box.  Mirrors
+``HiSpmvHandle::getPreparedMtx`` (common/src/spmv-helper.cpp:800-802)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import lib, HISPMV_OK
+
+
+@dataclass
+class Prepared:
+    rows: int
+    cols: int
+    nnz: int
+    n_elems: int
+    n_slices: int
+    slice_elems: int
+    stream_bytes: int
+    row_ptr: np.ndarray    # int64 [rows+1]
+    col_idx: np.ndarray    # int32 [nnz]
+    values: np.ndarray     # float32 [nnz]
+    words: np.ndarray      # uint64 [n_slices*slice_elems]: low 32 = fp32 bits, high 32 = rowEnd<<31 | col
+    hdr: np.ndarray        # int32 [n_slices,4]: row_base, chain_len, x_base, x_span
+    fix: np.ndarray        # int32 [n_split,4]: row, first_slice, len, 0
+
+
+def _collect(p) -> Prepared:
+    d = (C.c_int64 * 8)()
+    lib.hispmv_prep_dims(p, d)
+    rows, cols, nnz, n_elems, n_slices, se, n_fix, nbytes = (int(v) for v in d)
+
+    def arr(ptr, n, shape=None):
+        if n == 0:   # an empty std::vector hands out a NULL data pointer
+            a = np.zeros(0, dtype=np.ctypeslib.as_ctypes_type(ptr._type_))
+        else:
+            a = np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+        return a.reshape(shape) if shape else a
+    out = Prepared(rows, cols, nnz, n_elems, n_slices, se, nbytes,
+                   arr(lib.hispmv_prep_csr_row_ptr(p), rows + 1),
+                   arr(lib.hispmv_prep_csr_col(p), nnz),
+                   arr(lib.hispmv_prep_csr_val(p), nnz),
+                   arr(lib.hispmv_prep_words(p), n_slices * se),
+                   arr(lib.hispmv_prep_slice_hdr(p), n_slices * 4, (-1, 4)),
+                   arr(lib.hispmv_prep_fix(p), n_fix * 4, (-1, 4)))
+    lib.hispmv_prep_free(p)
+    return out
+
+
+def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int) -> Prepared:
+    r = np.ascontiguousarray(coo_rows, dtype=np.int32)
+    c = np.ascontiguousarray(coo_cols, dtype=np.int32)
+    v = np.ascontiguousarray(coo_values, dtype=np.float32)
+    p = C.c_void_p()
+    rc = lib.hispmv_prep_from_coo(C.byref(p), C.c_void_p(r.ctypes.data), C.c_void_p(c.ctypes.data),
+                                  C.c_void_p(v.ctypes.data), r.size, rows, cols)
+    if rc != HISPMV_OK:
+        raise ValueError(lib.hispmv_prep_last_error().decode())
+    return _collect(p)
+
+
+def prep_from_mtx(path, flavor: int = 0) -> Prepared:
+    p = C.c_void_p()
+    rc = lib.hispmv_prep_from_mtx(C.byref(p), str(path).encode(), int(flavor))
+    if rc != HISPMV_OK:
+        raise OSError(lib.hispmv_prep_last_error().decode())
+    return _collect(p)

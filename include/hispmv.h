@@ -1,0 +1,150 @@
+/* hispmv.h -- C ABI of libhispmv.so, the MI355X (gfx950) drop-in for the SpMV hot path of
+ * mfkiwl/HiSpMV:  y = alpha * A * x + beta * bias,  A sparse (slice stream) or dense (GeMV overlay).
+ *
+ * Every entry point replaces one piece of the reference's pybind11 class FpgaHandle
+ * (pyhispmv/include/fpga_handle.h:9-74, pyhispmv/src/fpga_handle.cpp, bound in
+ * pyhispmv/src/pyhispmv_bindings.cpp:3-39).  The reference-side binding a maintainer
+ * would write against this header is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; all functions return 0 (or a handle index
+ * >= 0) on success, HISPMV_FULL (-1) where the reference returns -1, and another negative
+ * HISPMV_E* code otherwise -- never exit(), never a C++ exception across the boundary
+ * (the reference calls std::exit on device errors, fpga_handle.cpp:58-64,82-88,267-270).
+ * hispmv_last_error() gives the message.  Calls on one context are serialised internally.
+ * Host pointers are borrowed for the duration of the call only.
+ */
+#ifndef HISPMV_H
+#define HISPMV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HISPMV_OK          0
+#define HISPMV_FULL       -1   /* matrix does not fit the arena (fpga_handle.cpp:192-195,235-238) */
+#define HISPMV_EINVAL     -2   /* bad argument (negative device id, empty path, bad shape, index out of range) */
+#define HISPMV_EDEVICE    -3   /* HIP runtime error / no gfx950 device */
+#define HISPMV_ESTATE     -4   /* call out of order (run before load/select) */
+#define HISPMV_ENOTDENSE  -5   /* dense handle requested on a context created without dense_overlay (spmv-helper.cpp:718) */
+#define HISPMV_EIO        -6   /* MatrixMarket file unreadable / malformed */
+#define HISPMV_ENOMEM     -7
+
+typedef struct hispmv_ctx hispmv_ctx;
+
+/* ---- FpgaHandle::FpgaHandle (fpga_handle.cpp:40-154; bindings :8-12) -------------------------
+ * xclbin_path is accepted for signature compatibility; it must be non-empty (fpga_handle.cpp:70-71)
+ * but is not opened.  device_id is the HIP device ordinal; negative is an error (:51-52).
+ * The hardware tuple (num_ch_A.. row_dist_net) is recorded: dense_overlay gates
+ * hispmv_create_dense_handle exactly as in the reference, num_ch_A sizes the default arena
+ * (num_ch_A x 256 MiB, fpga_handle.h:12) unless HISPMV_ARENA_BYTES / hispmv_set_arena_bytes overrides it. */
+int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int device_id,
+                  int num_ch_A, int num_ch_B, int num_ch_C, int urams_per_pe, int fp_acc_latency,
+                  int dense_overlay, int pre_accumulator, int row_dist_net);
+
+/* The reference never frees its handles (fpga_handle.cpp:177,220); we do. */
+void hispmv_destroy(hispmv_ctx* ctx);
+
+/* Message of the last failing call on ctx (or of the last failing hispmv_create when ctx is NULL). */
+const char* hispmv_last_error(const hispmv_ctx* ctx);
+
+/* Arena budget in bytes shared by all handles of the context ("-1 when full" contract). */
+int hispmv_set_arena_bytes(hispmv_ctx* ctx, int64_t bytes);
+int64_t hispmv_arena_bytes_used(const hispmv_ctx* ctx);
+
+/* ---- FpgaHandle::createSparseMtxHandle (fpga_handle.cpp:156-207; bindings :20-23) --------------
+ * COO triplets, unsorted and duplicated entries allowed (duplicates are summed by the
+ * multiply, not coalesced -- spmv-helper.cpp:139-227).  Returns the handle index (0,1,2.. in
+ * creation order), HISPMV_FULL, or an error. */
+int hispmv_create_sparse_handle(hispmv_ctx* ctx, const int32_t* coo_rows, const int32_t* coo_cols,
+                                const float* coo_values, int64_t nnz, int32_t rows, int32_t cols);
+
+/* HiSpmvHandle::prepareSparseMtxForFPGA(mtx_file) (spmv-helper.cpp:642-646): MatrixMarket
+ * coordinate file.  flavor 0 = common/ loader semantics (spmv-helper.cpp:34-136), 1 = cpu/ loader
+ * semantics (cpu/src/helper_functions.cpp:91-146). */
+int hispmv_create_sparse_handle_from_mtx(hispmv_ctx* ctx, const char* mtx_path, int flavor);
+
+/* CSR input (what cpu/src/main.cpp:26-33 hands MKL): row_ptr[rows+1], columns ascending per row. */
+int hispmv_create_sparse_handle_from_csr(hispmv_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx,
+                                         const float* values, int32_t rows, int32_t cols);
+
+/* ---- FpgaHandle::createDenseMtxHandle (fpga_handle.cpp:209-250; bindings :15-18) ---------------
+ * Row-major rows x cols fp32. */
+int hispmv_create_dense_handle(hispmv_ctx* ctx, const float* flattened_dense_values, int32_t rows, int32_t cols);
+
+/* ---- FpgaHandle::loadMatrices (fpga_handle.cpp:252-264) -----------------------------------------
+ * Uploads every handle created so far to HBM.  Idempotent (the reference corrupts its offsets
+ * when called twice, :259-261 -- not replicated). */
+int hispmv_load_matrices(hispmv_ctx* ctx);
+
+/* ---- FpgaHandle::selectMatrix (fpga_handle.cpp:266-283) -----------------------------------------
+ * Out of range -> HISPMV_EINVAL (reference: exit, :267-270). */
+int hispmv_select_matrix(hispmv_ctx* ctx, uint32_t matrix_idx);
+
+/* ---- FpgaHandle::runKernel (fpga_handle.cpp:286-321) --------------------------------------------
+ * y = alpha * A * x + beta * bias for the selected matrix; x[cols], bias[rows] read-only,
+ * y[rows] written; blocking.  bias is not read when beta == 0 (BLAS/MKL convention, cpu/src/main.cpp:39). */
+int hispmv_run_kernel(hispmv_ctx* ctx, const float* x, const float* bias, float* y, float alpha, float beta);
+
+/* ---- FpgaHandle::runLinear (fpga_handle.cpp:323-388) --------------------------------------------
+ * alpha = beta = 1; num_vecs = x_len / cols; y_out[num_vecs * rows]; same bias for every vector;
+ * independent of the select_matrix state. */
+int hispmv_linear(hispmv_ctx* ctx, int matrix_idx, const float* x, int64_t x_len, const float* bias, float* y_out);
+
+/* ---- device-resident entry points (no counterpart in the reference, whose vectors always cross
+ * PCIe -- fpga_handle.cpp:306-320).  d_* are device pointers; the launch is asynchronous on
+ * `stream` (a hipStream_t, NULL = the context's stream).  Used by bench.py and the multi-GPU driver. */
+int hispmv_spmv_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, const float* d_bias, float* d_y,
+                       float alpha, float beta, void* stream);
+int hispmv_synchronize(hispmv_ctx* ctx);
+
+/* Whole-kernel device time of the last hispmv_spmv_device/run_kernel/linear launch sequence,
+ * measured with HIP events on the launch stream (milliseconds); negative if unavailable. */
+float hispmv_last_kernel_ms(hispmv_ctx* ctx);
+
+/* Time `reps` back-to-back launches of matrix_idx on the context stream with HIP events
+ * (kernel-only, the reference's convention: spmv-helper.cpp:1030-1035).  Returns ms per launch. */
+float hispmv_time_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, const float* d_bias, float* d_y,
+                         float alpha, float beta, int reps);
+
+/* ---- getters (HiSpmvHandle getters, spmv-helper.cpp:752-810) ------------------------------------ */
+typedef struct hispmv_matrix_info {
+    int32_t rows, cols;
+    int64_t nnz;            /* getNNZ */
+    int32_t is_dense;       /* isDense */
+    int32_t loaded;
+    int64_t n_slices;       /* wavefront slices (the analogue of getRunLength's beats) */
+    int64_t n_elems;        /* stream elements before tail padding (nnz + empty-row fillers) */
+    int64_t n_split_rows;   /* rows shared between slices (the analogue of the shared-row list) */
+    int64_t device_bytes;   /* bytes this handle takes in the arena */
+    double prep_seconds;    /* host preprocessing time ("Pre-processing Time") */
+} hispmv_matrix_info;
+int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
+int hispmv_num_matrices(const hispmv_ctx* ctx);
+
+/* ---- host-only preprocessor access (no device needed): lets tests check the CSR indices and the
+ * packed stream against the oracle on a CPU-only box.  Mirrors HiSpmvHandle::getPreparedMtx
+ * (spmv-helper.cpp:800-802). ------------------------------------------------------------------- */
+typedef struct hispmv_prep hispmv_prep;
+int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* coo_rows, const int32_t* coo_cols,
+                         const float* coo_values, int64_t nnz, int32_t rows, int32_t cols);
+int hispmv_prep_from_mtx(hispmv_prep** out, const char* mtx_path, int flavor);
+void hispmv_prep_free(hispmv_prep* p);
+const char* hispmv_prep_last_error(void);
+/* dims[0..7] = rows, cols, nnz, n_elems, n_slices, slice_elems, n_split_rows, stream_bytes */
+int hispmv_prep_dims(const hispmv_prep* p, int64_t dims[8]);
+const int64_t* hispmv_prep_csr_row_ptr(const hispmv_prep* p);
+const int32_t* hispmv_prep_csr_col(const hispmv_prep* p);
+const float* hispmv_prep_csr_val(const hispmv_prep* p);
+const uint64_t* hispmv_prep_words(const hispmv_prep* p);     /* n_slices * slice_elems 64-bit words */
+const int32_t* hispmv_prep_slice_hdr(const hispmv_prep* p);   /* n_slices x {row_base, chain_len, x_base, x_span} */
+const int32_t* hispmv_prep_fix(const hispmv_prep* p);         /* n_split_rows x {row, first_slice, len, 0} */
+
+/* Library identification: "hispmv-amd <version> gfx950". */
+const char* hispmv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HISPMV_H */

@@ -1,0 +1,294 @@
+"""Parity of the HIP path (through the C ABI / FpgaHandle facade) against the oracle, on a real
+MI355X.  Tolerance: BASELINE.json north_star -- indices bit-exact (checked on the host in
+test_prep_host.py), y within 1e-5 relative fp32, evaluated in backward-error form
+|dy_i| <= 1e-5 * (|alpha| sum_j |a_ij x_j| + |beta b_i|) against an fp64 accumulation."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ALPHA, ALPHA_HOST, BETA, BETA_HOST, GOLDEN, GOLDEN_CASES, TOL, ref_vectors
+from util import bwd_err
+
+pytestmark = pytest.mark.gpu
+
+HW = ("tests.xclbin", 0, 24, 1, 1, 2, 5, True, False, True)   # apps/general_test.py:10-19
+
+
+@pytest.fixture(scope="module")
+def pyhispmv_mod():
+    import pyhispmv
+    return pyhispmv
+
+
+@pytest.fixture()
+def fpga(pyhispmv_mod):
+    h = pyhispmv_mod.FpgaHandle(*HW)
+    yield h
+    h.close()
+
+
+def csr_truth(r, c, v, rows, x, b, alpha, beta):
+    order = np.lexsort((c, r))
+    rp = np.zeros(rows + 1, np.int64)
+    np.add.at(rp, np.asarray(r, np.int64) + 1, 1)
+    rp = np.cumsum(rp).astype(np.int32)
+    return oracle.spmv_f64(rp, np.asarray(c, np.int32)[order], np.asarray(v, np.float32)[order], x, b, alpha, beta)
+
+
+def test_native_library_is_loaded(pyhispmv_mod):
+    from hispmv_amd import _lib
+    assert _lib.LIB_PATH.exists()
+    maps = open("/proc/self/maps").read()
+    assert "libhispmv.so" in maps
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
+    from hispmv_amd.prep import prep_from_mtx
+    g = golden(name)
+    idx = fpga.create_sparse_handle_from_mtx(GOLDEN / f"{name}.mtx", 1)
+    assert idx == 0
+    fpga.load_matrices()
+    fpga.select_matrix(idx)
+    rows, cols = int(g["rows"]), int(g["cols"])
+    x, y0 = ref_vectors(rows, cols)
+    y = np.full(rows, np.nan, np.float32)
+    fpga.run_kernel(x, y0, y, ALPHA, BETA)
+    y64, mag = oracle.spmv_f64(g["ref_row_ptr"], g["ref_col_idx"], g["ref_vals"], x, y0, ALPHA, BETA)
+    assert bwd_err(y, y64, mag) < TOL
+    assert float(np.max(np.abs(y.astype(np.float64) - g["y_mkl"]) / mag)) < 2 * TOL     # vs the cpu/ MKL path
+    pl, mre, _ = oracle.precision_loss(g["y_mkl"], y)                                    # the reference's own metric
+    assert pl < 1e-5
+    # the CPU model of the wavefront performs the same fp32 operations in the same order
+    P = prep_from_mtx(GOLDEN / f"{name}.mtx", 1)
+    ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, rows)
+    assert np.array_equal(y.view(np.uint32), ye.view(np.uint32)), "GPU result differs bitwise from the wavefront model"
+    info = fpga.matrix_info(idx)
+    assert info["nnz"] == g["ref_col_idx"].size and info["loaded"] == 1 and not info["is_dense"]
+
+
+def test_general_test_call_sequence_scaled(fpga):
+    """apps/general_test.py:22-113 with the same call order, dense 5000x1000 + 100 k random COO
+    (duplicates included), checked with the script's own np.allclose(rtol=1e-3) and the 1e-5 gate."""
+    from scipy.sparse import coo_matrix
+    np.random.seed(0)
+    rows, cols = 5000, 1000
+    dense_values = np.random.rand(rows, cols).astype(np.float32)
+    x = np.random.rand(cols).astype(np.float32)
+    bias = np.random.rand(rows).astype(np.float32)
+    y_dense = np.zeros(rows, dtype=np.float32)
+    y_dense_expected = np.dot(dense_values, x) + bias
+    nnz = 100000
+    coo_rows = np.random.randint(0, rows, size=nnz, dtype=np.int32)
+    coo_cols = np.random.randint(0, cols, size=nnz, dtype=np.int32)
+    coo_values = np.random.rand(nnz).astype(np.float32)
+    y_sparse = np.zeros(rows, dtype=np.float32)
+    y_sparse_expected = coo_matrix((coo_values, (coo_rows, coo_cols)), shape=(rows, cols)).dot(x) + bias
+    dense_handle_idx = fpga.create_dense_handle(dense_values.flatten(), rows, cols)
+    sparse_handle_idx = fpga.create_sparse_handle(coo_rows, coo_cols, coo_values, rows, cols)
+    assert (dense_handle_idx, sparse_handle_idx) == (0, 1)
+    fpga.load_matrices()
+    fpga.select_matrix(dense_handle_idx)
+    fpga.run_kernel(x, bias, y_dense, 1.0, 1.0)
+    fpga.select_matrix(sparse_handle_idx)
+    fpga.run_kernel(x, bias, y_sparse, 1.0, 1.0)
+    assert np.allclose(y_dense, y_dense_expected, rtol=1e-3)
+    assert np.allclose(y_sparse, y_sparse_expected, rtol=1e-3)
+    y64, mag = csr_truth(coo_rows, coo_cols, coo_values, rows, x, bias, 1.0, 1.0)
+    assert bwd_err(y_sparse, y64, mag) < TOL
+    d64 = dense_values.astype(np.float64) @ x.astype(np.float64) + bias
+    assert bwd_err(y_dense, d64, np.abs(dense_values.astype(np.float64)) @ np.abs(x.astype(np.float64)) + np.abs(bias)) < TOL
+    assert np.array_equal(y_dense.view(np.uint32), oracle.emu_gemv(dense_values, x, bias, 1.0, 1.0).view(np.uint32))
+
+
+def test_model_test_call_sequence_scaled(fpga):
+    """apps/model_test.py + fpga_layer_manager.py:54-81 + model.py:68-80: dense layer, two sparse
+    layers (densities 0.1 / 0.25), ReLU between, `linear(idx, x_flat, bias)` per layer."""
+    rng = np.random.default_rng(0)
+    sizes = [(1024, 512, None), (1024, 1024, 0.1), (256, 1024, 0.25)]     # (out, in, density)
+    Ws, bs, idxs = [], [], []
+    for out_f, in_f, dens in sizes:
+        W = rng.standard_normal((out_f, in_f), dtype=np.float32)
+        if dens is not None:
+            W *= rng.random((out_f, in_f)) < dens
+        b = rng.standard_normal(out_f, dtype=np.float32)
+        density = np.count_nonzero(W) / W.size
+        if density > 0.5:                                                  # fpga_layer_manager.py:43-47
+            idx = fpga.create_dense_handle(W.flatten(), *W.shape)
+        else:
+            rr, cc = np.nonzero(W)
+            idx = fpga.create_sparse_handle(rr.astype(np.int64), cc.astype(np.int64), W[rr, cc], *W.shape)   # int64 like torch
+        assert idx >= 0
+        Ws.append(W); bs.append(b); idxs.append(idx)
+    fpga.load_matrices()
+    x = rng.standard_normal(512, dtype=np.float32)
+    h, h64 = x, x.astype(np.float64)
+    for W, b, idx in zip(Ws, bs, idxs):
+        y = fpga.linear(idx, h, b)
+        assert y.shape == (W.shape[0],)
+        y64 = W.astype(np.float64) @ h.astype(np.float64) + b
+        mag = np.abs(W.astype(np.float64)) @ np.abs(h.astype(np.float64)) + np.abs(b)
+        assert bwd_err(y, y64, mag) < TOL
+        h = np.maximum(y, 0)
+    # batched linear: num_vecs = len(x)//cols, same bias for every vector (fpga_handle.cpp:336-339)
+    xb = rng.standard_normal(3 * 512, dtype=np.float32)
+    yb = fpga.linear(idxs[0], xb, bs[0])
+    assert yb.shape == (3 * 1024,)
+    for k in range(3):
+        assert np.array_equal(yb[k * 1024:(k + 1) * 1024], fpga.linear(idxs[0], xb[k * 512:(k + 1) * 512], bs[0]))
+
+
+@pytest.mark.parametrize("alpha,beta", [(ALPHA_HOST, BETA_HOST), (1.0, 0.0), (0.0, 1.0), (-1.5, 0.5)])
+def test_power_law_and_heavy_rows(fpga, alpha, beta):
+    rng = np.random.default_rng(7)
+    rows, cols, nnz = 60000, 50000, 1500000
+    w = 1.0 / (np.arange(rows) + 1.0) ** 1.2
+    r = rng.choice(rows, size=nnz, p=w / w.sum()).astype(np.int32)          # Zipf row lengths, many empty rows
+    c = rng.integers(0, cols, nnz).astype(np.int32)
+    v = (rng.random(nnz, dtype=np.float32) - 0.5)
+    idx = fpga.create_sparse_handle(r, c, v, rows, cols)
+    fpga.load_matrices()
+    info = fpga.matrix_info(idx)
+    assert info["n_split_rows"] > 0 and info["n_elems"] > info["nnz"]        # shared rows and empty-row fillers exist
+    x = rng.random(cols, dtype=np.float32)
+    b = rng.random(rows, dtype=np.float32) if beta != 0 else np.full(rows, np.nan, np.float32)
+    y = np.zeros(rows, np.float32)
+    fpga.select_matrix(idx)
+    fpga.run_kernel(x, b, y, alpha, beta)
+    y64, mag = csr_truth(r, c, v, rows, x, np.nan_to_num(b), alpha, beta)
+    assert np.isfinite(y).all() and bwd_err(y, y64, mag) < TOL
+    y2 = np.zeros(rows, np.float32)
+    fpga.run_kernel(x, b, y2, alpha, beta)
+    assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))             # no atomics: bitwise reproducible
+
+
+def test_adversarial_full_row_plus_diagonal(fpga):
+    n = 300000
+    r = np.concatenate([np.arange(n), np.full(n, 12345)]).astype(np.int32)
+    c = np.concatenate([np.arange(n), np.arange(n)]).astype(np.int32)
+    rng = np.random.default_rng(1)
+    v = rng.random(2 * n, dtype=np.float32) + 0.5
+    idx = fpga.create_sparse_handle(r, c, v, n, n)
+    fpga.load_matrices()
+    assert fpga.matrix_info(idx)["n_split_rows"] >= 1
+    x, y0 = ref_vectors(n, n)
+    y = np.zeros(n, np.float32)
+    fpga.select_matrix(idx)
+    fpga.run_kernel(x, y0, y, ALPHA, BETA)
+    y64, mag = csr_truth(r, c, v, n, x, y0, ALPHA, BETA)
+    assert bwd_err(y, y64, mag) < TOL
+
+
+def test_full_size_suitesparse_shape_properties(fpga):
+    """A BASELINE-size stand-in (crankseg_2 shape: 63 838 rows, 14.1 M nnz) checked through
+    size-independent properties: linearity in x, A*1 = row sums, alpha/beta scaling."""
+    from hispmv_amd.matrices import synth_banded
+    rows, nnz = 63838, 14148850
+    rp, ci, va = synth_banded(rows, rows, nnz, bandwidth=4000, seed=2)
+    idx = fpga.create_sparse_handle_from_csr(rp, ci, va, rows, rows)
+    fpga.load_matrices()
+    fpga.select_matrix(idx)
+    ones = np.ones(rows, np.float32)
+    zero = np.zeros(rows, np.float32)
+    y1 = np.zeros(rows, np.float32)
+    fpga.run_kernel(ones, zero, y1, 1.0, 0.0)
+    rowsum = np.add.reduceat(va.astype(np.float64), rp[:-1].astype(np.int64)) * (np.diff(rp) > 0)
+    mag = np.add.reduceat(np.abs(va.astype(np.float64)), rp[:-1].astype(np.int64)) * (np.diff(rp) > 0)
+    assert bwd_err(y1, rowsum, np.maximum(mag, 1e-30)) < TOL
+    rng = np.random.default_rng(4)
+    xa = rng.integers(-8, 9, rows).astype(np.float32)
+    xb = rng.integers(-8, 9, rows).astype(np.float32)
+    ya, yb, yab = (np.zeros(rows, np.float32) for _ in range(3))
+    fpga.run_kernel(xa, zero, ya, 1.0, 0.0)
+    fpga.run_kernel(xb, zero, yb, 1.0, 0.0)
+    fpga.run_kernel(xa + xb, zero, yab, 1.0, 0.0)
+    scale = np.maximum(mag * 16, 1e-30)
+    assert float(np.max(np.abs(yab.astype(np.float64) - ya - yb) / scale)) < 3 * TOL
+    y2 = np.zeros(rows, np.float32)
+    fpga.run_kernel(xa, ones, y2, 2.0, 3.0)
+    assert float(np.max(np.abs(y2.astype(np.float64) - (2.0 * ya.astype(np.float64) + 3.0)) / np.maximum(scale, 3.0))) < 3 * TOL
+    y64, m64 = oracle.spmv_f64(rp, ci, va, xa, zero, 1.0, 0.0)
+    assert bwd_err(ya, y64, np.maximum(m64, 1e-30)) < TOL
+
+
+def test_dense_shapes_and_unaligned_columns(fpga):
+    rng = np.random.default_rng(9)
+    shapes = [(1, 1), (3, 7), (130, 1001), (257, 4096), (1000, 2500)]
+    idxs = []
+    mats = []
+    for rws, cls in shapes:
+        W = rng.random((rws, cls), dtype=np.float32) - 0.5
+        idxs.append(fpga.create_dense_handle(W.flatten(), rws, cls))
+        mats.append(W)
+    fpga.load_matrices()
+    for idx, W in zip(idxs, mats):
+        rws, cls = W.shape
+        x = rng.random(cls, dtype=np.float32)
+        b = rng.random(rws, dtype=np.float32)
+        y = np.zeros(rws, np.float32)
+        fpga.select_matrix(idx)
+        fpga.run_kernel(x, b, y, ALPHA, BETA)
+        ref = ALPHA * (W.astype(np.float64) @ x.astype(np.float64)) + BETA * b.astype(np.float64)
+        mag = abs(ALPHA) * (np.abs(W.astype(np.float64)) @ np.abs(x.astype(np.float64))) + np.abs(BETA * b.astype(np.float64))
+        assert bwd_err(y, ref, mag) < TOL
+        assert np.array_equal(y.view(np.uint32), oracle.emu_gemv(W, x, b, ALPHA, BETA).view(np.uint32))
+        yn = oracle.naive_gemv(W, x, b, ALPHA, BETA)           # cpu/src/main.cpp:53-71
+        assert bwd_err(yn, ref, mag) < TOL
+
+
+def test_capacity_and_error_contract(pyhispmv_mod):
+    h = pyhispmv_mod.FpgaHandle(*HW)
+    h.set_arena_bytes(1 << 20)
+    W = np.ones((600, 600), np.float32)                          # 1.44 MB > 1 MiB
+    assert h.create_dense_handle(W.flatten(), 600, 600) == -1    # fpga_handle.cpp:235-238
+    small = h.create_dense_handle(W[:100, :100].flatten(), 100, 100)
+    assert small == 0
+    r = np.arange(200000, dtype=np.int32) % 1000
+    assert h.create_sparse_handle(r, r, np.ones(r.size, np.float32), 1000, 1000) == -1   # :192-195
+    with pytest.raises(AssertionError):
+        h.run_kernel(np.ones(100, np.float32), np.ones(100, np.float32), np.zeros(100, np.float32), 1.0, 1.0)  # nothing selected (:292)
+    with pytest.raises(IndexError):
+        h.select_matrix(5)                                       # :267-270
+    h.select_matrix(small)
+    with pytest.raises(AssertionError):                          # not loaded yet
+        h.run_kernel(np.ones(100, np.float32), np.ones(100, np.float32), np.zeros(100, np.float32), 1.0, 1.0)
+    h.load_matrices()
+    h.load_matrices()                                            # idempotent (reference: corrupts offsets, :259-261)
+    y = np.zeros(100, np.float32)
+    h.run_kernel(np.ones(100, np.float32), np.ones(100, np.float32), y, 1.0, 1.0)
+    assert np.all(y == 101.0)
+    with pytest.raises(TypeError):
+        h.run_kernel(np.ones(100, np.float32), np.ones(100, np.float32), np.zeros(100, np.float64), 1.0, 1.0)
+    with pytest.raises(ValueError):
+        h.create_sparse_handle([0, 2000], [0, 0], [1.0, 1.0], 1000, 1000)   # index outside the matrix
+    h.close()
+    nd = pyhispmv_mod.FpgaHandle("t.xclbin", 0, 16, 1, 4, 2, 5, False, False, True)   # no dense overlay
+    with pytest.raises(AssertionError):
+        nd.create_dense_handle(np.ones(4, np.float32), 2, 2)        # spmv-helper.cpp:718
+    nd.close()
+    with pytest.raises(RuntimeError):
+        pyhispmv_mod.FpgaHandle("t.xclbin", 64, 24, 1, 1, 2, 5, True, False, True)   # no such device
+
+
+def test_device_resident_entry_point_matches_host_path(fpga):
+    import torch
+    rng = np.random.default_rng(11)
+    rows, cols, nnz = 20000, 20000, 300000
+    r = rng.integers(0, rows, nnz).astype(np.int32)
+    c = rng.integers(0, cols, nnz).astype(np.int32)
+    v = rng.random(nnz, dtype=np.float32) - 0.5
+    idx = fpga.create_sparse_handle(r, c, v, rows, cols)
+    fpga.load_matrices()
+    x = rng.random(cols, dtype=np.float32)
+    b = rng.random(rows, dtype=np.float32)
+    y = np.zeros(rows, np.float32)
+    fpga.select_matrix(idx)
+    fpga.run_kernel(x, b, y, ALPHA, BETA)
+    dx, db = torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda()
+    dy = torch.zeros(rows, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    fpga.spmv_device(idx, dx.data_ptr(), db.data_ptr(), dy.data_ptr(), ALPHA, BETA, stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy().view(np.uint32), y.view(np.uint32))
+    ms = fpga.time_device(idx, dx.data_ptr(), db.data_ptr(), dy.data_ptr(), ALPHA, BETA, 20)
+    assert 0 < ms < 50

@@ -1,0 +1,185 @@
+"""Host preprocessor of libhispmv.so (COO / MatrixMarket -> CSR -> slice stream), CPU only.
+Index parity is bit-exact against the reference loader's outputs in tests/golden; the packed
+stream is decoded with the oracle's wavefront model and compared with the fp64 truth."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import oracle
+from conftest import ALPHA, BETA, GOLDEN, GOLDEN_CASES, TOL, ref_vectors
+from hispmv_amd.prep import prep_from_coo, prep_from_mtx
+from util import bwd_err
+
+ROW_END = np.uint64(1) << np.uint64(63)
+
+
+def decode(P):
+    meta = (P.words >> np.uint64(32)).astype(np.uint32)
+    col = (meta & np.uint32(0x7FFFFFFF)).astype(np.int64)
+    end = (meta >> np.uint32(31)).astype(bool)
+    val = (P.words & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32)
+    return col, end, val
+
+
+def check_stream_invariants(P):
+    col, end, val = decode(P)
+    lens = np.diff(P.row_ptr)
+    n_empty = int(np.sum(lens == 0))
+    assert P.n_elems == P.nnz + n_empty
+    assert P.n_slices == -(-P.n_elems // P.slice_elems)
+    assert P.words.size == P.n_slices * P.slice_elems
+    assert int(end.sum()) == P.rows                      # exactly one row end per row
+    assert not end[P.n_elems:].any() and np.all(val[P.n_elems:] == 0)   # tail padding is inert
+    # element order is CSR order with one zero filler per empty row
+    keep = np.ones(P.n_elems, bool)
+    eoff = np.concatenate([[0], np.cumsum(np.maximum(lens, 1))])
+    keep[eoff[:-1][lens == 0]] = False
+    assert np.array_equal(col[:P.n_elems][keep], P.col_idx)
+    assert np.array_equal(val[:P.n_elems][keep].view(np.uint32), P.values.view(np.uint32))
+    assert np.all(val[:P.n_elems][~keep] == 0)
+    assert np.array_equal(np.nonzero(end)[0] + 1, eoff[1:])
+    # slice headers: row_base = row ends before the slice; window covers every referenced column
+    ends_before = np.concatenate([[0], np.cumsum(end)])[:: P.slice_elems][: P.n_slices]
+    assert np.array_equal(P.hdr[:, 0], ends_before)
+    c2 = col.reshape(P.n_slices, P.slice_elems)
+    assert np.all(c2 >= P.hdr[:, 2:3]) and np.all(c2 < (P.hdr[:, 2] + P.hdr[:, 3])[:, None])
+    assert np.all(col < max(P.cols, 1))
+    # split rows: (row, first_slice, len) consistent with the element offsets
+    for row, first, ln, _ in P.fix:
+        s_first, s_last = eoff[row] // P.slice_elems, (eoff[row + 1] - 1) // P.slice_elems
+        assert (first, ln) == (s_first, s_last - s_first) and ln > 0
+        assert P.hdr[s_last, 1] == ln
+    n_split = int(np.sum(eoff[:-1] // P.slice_elems != (eoff[1:] - 1) // P.slice_elems))
+    assert len(P.fix) == n_split and int(np.sum(P.hdr[:, 1] > 0)) == n_split
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_csr_indices_bit_exact_vs_reference_loader(name, golden):
+    g = golden(name)
+    P = prep_from_mtx(GOLDEN / f"{name}.mtx", flavor=1)     # cpu/ loader semantics
+    assert (P.rows, P.cols) == (int(g["rows"]), int(g["cols"]))
+    assert np.array_equal(P.row_ptr.astype(np.int32), g["ref_row_ptr"])
+    assert np.array_equal(P.col_idx, g["ref_col_idx"])
+    assert np.array_equal(P.values.view(np.uint32), g["ref_vals"].view(np.uint32))
+    check_stream_invariants(P)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_common_flavour_matches_loadmtx_restatement(name, golden):
+    g = golden(name)
+    P = prep_from_mtx(GOLDEN / f"{name}.mtx", flavor=0)     # common/ loadMtx semantics
+    Q = prep_from_coo(g["coo_r"], g["coo_c"], g["coo_v"], P.rows, P.cols)
+    for a, b in ((P.row_ptr, Q.row_ptr), (P.col_idx, Q.col_idx), (P.values.view(np.uint32), Q.values.view(np.uint32)),
+                 (P.words, Q.words), (P.hdr, Q.hdr), (P.fix, Q.fix)):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_stream_decodes_to_mkl_result(name, golden):
+    g = golden(name)
+    P = prep_from_mtx(GOLDEN / f"{name}.mtx", flavor=1)
+    x, y0 = ref_vectors(P.rows, P.cols)
+    y = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, P.rows)
+    y64, mag = oracle.spmv_f64(g["ref_row_ptr"], g["ref_col_idx"], g["ref_vals"], x, y0, ALPHA, BETA)
+    assert bwd_err(y, y64, mag) < TOL
+    # and directly against the MKL vector (both fp32): within 2*TOL of each other in the same scale
+    assert float(np.max(np.abs(y.astype(np.float64) - g["y_mkl"]) / mag)) < 2 * TOL
+
+
+def test_product_reader_keeps_last_line_without_newline(tmp_path):
+    p = tmp_path / "nonl.mtx"
+    p.write_bytes((GOLDEN / "syn_1138.mtx").read_bytes().rstrip(b"\n"))
+    assert prep_from_mtx(p, 0).nnz == 4054      # the reference loses it; we do not
+
+
+def test_reader_rejects_what_the_reference_rejects(tmp_path):
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%NotMatrixMarket matrix coordinate real general\n1 1 1\n1 1 1.0\n")
+    with pytest.raises(OSError):
+        prep_from_mtx(bad)
+    arr = tmp_path / "arr.mtx"
+    arr.write_text("%%MatrixMarket matrix array real general\n1 1\n1.0\n")
+    with pytest.raises(OSError):
+        prep_from_mtx(arr)
+    cplx = tmp_path / "c.mtx"
+    cplx.write_text("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n")
+    with pytest.raises(OSError):
+        prep_from_mtx(cplx)
+    with pytest.raises(OSError):
+        prep_from_mtx(tmp_path / "missing.mtx")
+
+
+def test_duplicates_unsorted_and_stability():
+    # duplicates are kept as separate entries, in input order (general_test.py:42-44 relies on it)
+    r = np.array([2, 0, 2, 2, 0, 1], np.int32)
+    c = np.array([1, 3, 1, 0, 3, 2], np.int32)
+    v = np.array([1, 2, 3, 4, 5, 6], np.float32)
+    P = prep_from_coo(r, c, v, 3, 4)
+    assert P.row_ptr.tolist() == [0, 2, 3, 6]
+    assert P.col_idx.tolist() == [3, 3, 2, 0, 1, 1]
+    assert P.values.tolist() == [2, 5, 6, 4, 1, 3]
+    check_stream_invariants(P)
+
+
+def test_edge_shapes():
+    P = prep_from_coo([], [], [], 5, 7)                       # no nonzeros: five fillers
+    assert (P.nnz, P.n_elems, P.n_slices) == (0, 5, 1)
+    check_stream_invariants(P)
+    y = oracle.emu_spmv(P.words, P.hdr, P.fix, np.ones(7, np.float32), np.arange(5, dtype=np.float32), 2.0, 3.0, 5)
+    assert y.tolist() == [0, 3, 6, 9, 12]
+    P = prep_from_coo([0], [0], [2.5], 1, 1)
+    y = oracle.emu_spmv(P.words, P.hdr, P.fix, np.array([4], np.float32), np.array([1], np.float32), 1.0, 1.0, 1)
+    assert y.tolist() == [11.0]
+    # a row exactly filling a slice, and a row spanning 3 slices
+    n = 1024
+    r = np.concatenate([np.zeros(n), np.ones(2 * n + 10), np.full(3, 2)]).astype(np.int32)
+    c = np.concatenate([np.arange(n), np.arange(2 * n + 10), np.arange(3)]).astype(np.int32)
+    P = prep_from_coo(r, c, np.ones(r.size, np.float32), 3, 2 * n + 10)
+    check_stream_invariants(P)
+    assert P.fix.tolist() == [[1, 1, 2, 0]]
+    y = oracle.emu_spmv(P.words, P.hdr, P.fix, np.ones(2 * n + 10, np.float32), np.zeros(3, np.float32), 1.0, 0.0, 3)
+    assert y.tolist() == [n, 2 * n + 10, 3]
+
+
+def test_index_out_of_range_is_an_error():
+    with pytest.raises(ValueError):
+        prep_from_coo([0, 5], [0, 0], [1.0, 1.0], 5, 3)
+    with pytest.raises(ValueError):
+        prep_from_coo([0], [-1], [1.0], 5, 3)
+
+
+def test_heavy_row_and_empty_rows_large():
+    rng = np.random.default_rng(3)
+    rows, cols, nnz = 20000, 15000, 400000
+    r = rng.integers(0, rows, nnz)
+    r[:100000] = 1234                       # one row spanning ~98 slices (long fix-up chain)
+    r[r % 5 == 0] += 1                      # rows = 0 mod 5 stay empty
+    c = rng.integers(0, cols, nnz)
+    v = rng.random(nnz, dtype=np.float32) - 0.5
+    P = prep_from_coo(r, c, v, rows, cols)
+    check_stream_invariants(P)
+    assert P.fix[:, 2].max() > 32          # exercises the wave-per-entry fix-up model
+    x = rng.random(cols, dtype=np.float32)
+    b = rng.random(rows, dtype=np.float32)
+    y = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, 0.55, -2.05, rows)
+    y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, 0.55, -2.05)
+    assert bwd_err(y, y64, mag) < TOL
+    yb0 = oracle.emu_spmv(P.words, P.hdr, P.fix, x, np.full(rows, np.nan, np.float32), 0.55, 0.0, rows)
+    assert np.isfinite(yb0).all()          # beta == 0: bias is not read
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 60), st.integers(1, 60), st.integers(0, 3000), st.integers(0, 2**31 - 1))
+def test_property_random_coo_matches_scipy(rows, cols, nnz, seed):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, rows, nnz).astype(np.int32)
+    c = rng.integers(0, cols, nnz).astype(np.int32)
+    v = rng.integers(-4, 5, nnz).astype(np.float32)       # small integers: sums are exact in fp32
+    x = rng.integers(-3, 4, cols).astype(np.float32)
+    b = rng.integers(-3, 4, rows).astype(np.float32)
+    P = prep_from_coo(r, c, v, rows, cols)
+    check_stream_invariants(P)
+    y = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, 2.0, -1.0, rows)
+    ref = 2.0 * (sp.coo_matrix((v.astype(np.float64), (r, c)), shape=(rows, cols)) @ x.astype(np.float64)) - b
+    assert np.array_equal(y.astype(np.float64), ref)
