@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X: fp32 y = alpha*A*x + beta*y over the
+20-matrix SuiteSparse set of get_tb_matrices.py:57-78 (BASELINE.json configs[1]); metric = the
+reference's own GFLOP/s convention 2*(nnz+rows)/t (spmv-host.cpp:100,185) plus achieved HBM GB/s.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass over the set: one SpMV launch per matrix, back to back on one HIP stream,
+every operand already resident in HBM.  The working set of a step (~1.45 GB of packed stream) is
+far larger than the 256 MiB Infinity Cache, so every launch streams its matrix from HBM.
+SuiteSparse files cannot be downloaded here; matrices/<name>/<name>.mtx is used when present,
+otherwise the seeded stand-in with the real matrix's rows and nnz (hispmv_amd/matrices.py).
+
+N > 1 (weak scaling): rank k holds the k-th row block of the set scaled N-fold (same per-GPU nnz),
+split on the nnz prefix; x is replicated; the partial sums of rows cut by a rank boundary are
+exchanged with one RCCL all_gather per step (hispmv_amd/dist.py) -- never an all-reduce of y.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ALPHA, BETA = 0.55, -2.05            # common/src/spmv-host.cpp:43-44 (the FPGA/GPU drivers' scalars)
+HBM_PEAK_GBS = 8000.0                # MI355X spec (MI355X_MICROARCH.md, HBM)
+HW = ("bench.xclbin", 24, 1, 1, 2, 5, True, False, True)   # apps tuple; only sizes the default arena
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--matrices", type=str, default="", help="comma-separated subset of the set (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-matrix-reps", type=int, default=10)
+    ap.add_argument("--details", type=str, default="", help="write the per-matrix table to this JSON file")
+    return ap.parse_args()
+
+
+def load_set(names, rank, world):
+    """-> list of dicts with the rank's CSR shard of every matrix (host arrays)."""
+    from hispmv_amd import matrices as M
+    out = []
+    for name, rows, nnz, fam, bw in M.SUITESPARSE_SET:
+        if names and name not in names:
+            continue
+        real = M.real_matrix_path(name)
+        if real is not None and world == 1:
+            out.append(dict(name=name, source="file:" + str(real), path=str(real)))
+            continue
+        import zlib
+        seed = zlib.crc32(name.encode()) + rank       # rank k's block of the N-fold scaled matrix
+        rp, ci, va = M.synth_csr(rows, rows, nnz, fam, bw, seed)
+        out.append(dict(name=name, source=f"synthetic:{fam}", rows=rows, cols=rows, nnz=nnz, rp=rp, ci=ci, va=va))
+    return out
+
+
+def cpu_baseline(mats, budget_s=20.0):
+    """The oracle (kind "port") timed on the host cores over the same matrices: the OpenMP CSR
+    restatement of cpu/src/main.cpp:11-23 and, when the image has libmkl_rt, mkl_sparse_s_mv called
+    exactly as cpu/src/main.cpp:26-49 does (the reference's timed CPU path, 200 reps in
+    cpu/run_spmv.sh:6; here reps are bounded so the whole leg stays within ~budget_s)."""
+    import oracle   # checker/baseline only -- never on the product path
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    res = {"omp": [0.0, 0.0], "mkl": [0.0, 0.0]}
+    used = {"omp": cores, "mkl": 0}
+    per_matrix_budget = budget_s / max(1, len(mats)) / 2
+    sample = []
+    for m in mats:
+        if "rp" not in m:
+            continue
+        rows, cols, nnz = m["rows"], m["cols"], m["nnz"]
+        x = ((np.arange(cols, dtype=np.float32) + 1) / (np.arange(cols, dtype=np.float32) + 2)).astype(np.float32)
+        y0 = (np.float32(-2.0) * (np.arange(rows, dtype=np.float32) + 1) / (np.arange(rows, dtype=np.float32) + 2)).astype(np.float32)
+        fl = 2.0 * (nnz + rows)
+        t1, nt, _ = oracle.omp_spmv_timed(m["rp"], m["ci"], m["va"], x, y0, 0.85, -2.06, 1)
+        reps = int(min(200, max(2, per_matrix_budget / max(t1, 1e-6))))
+        t, nt, _ = oracle.omp_spmv_timed(m["rp"], m["ci"], m["va"], x, y0, 0.85, -2.06, reps)
+        res["omp"][0] += fl * reps; res["omp"][1] += t * reps; used["omp"] = nt
+        if oracle.mkl_available():
+            r1 = oracle.mkl_spmv(m["rp"], m["ci"], m["va"], cols, x, y0, 0.85, -2.06, 1, cores)
+            if r1 is not None:
+                reps_m = int(min(200, max(2, per_matrix_budget / max(r1[0], 1e-6))))
+                r = oracle.mkl_spmv(m["rp"], m["ci"], m["va"], cols, x, y0, 0.85, 0.0, reps_m, cores)
+                res["mkl"][0] += fl * reps_m; res["mkl"][1] += r[0] * reps_m; used["mkl"] = r[1]
+        sample.append(m["name"])
+    omp = res["omp"][0] / res["omp"][1] / 1e9 if res["omp"][1] > 0 else None
+    mkl = res["mkl"][0] / res["mkl"][1] / 1e9 if res["mkl"][1] > 0 else None
+    primary = "mkl_sparse_s_mv" if mkl is not None else "openmp_csr"
+    return {
+        "value": round(mkl if mkl is not None else omp, 3), "unit": "GFLOP/s",
+        "cores": used["mkl"] if mkl is not None else used["omp"], "kind": "port", "impl": primary,
+        "openmp_csr_gflops": None if omp is None else round(omp, 3),
+        "mkl_gflops": None if mkl is None else round(mkl, 3),
+        "sample": f"{len(sample)} matrices of the same set ({', '.join(sample[:3])}...), reps bounded to ~{budget_s:.0f} s total "
+                  f"(reference: 200 reps each, cpu/run_spmv.sh:6), alpha=0.85 beta=-2.06 as cpu/src/main.cpp:147-148",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import pyhispmv
+    from hispmv_amd import matrices as M
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    names = [n for n in args.matrices.split(",") if n]
+    t0 = time.time()
+    mats = load_set(names, rank, world)
+    t_gen = time.time() - t0
+
+    fpga = pyhispmv.FpgaHandle(HW[0], local_rank, *HW[1:])
+    fpga.set_arena_bytes(64 << 30)
+    t0 = time.time()
+    for m in mats:
+        if "path" in m:
+            m["idx"] = fpga.create_sparse_handle_from_mtx(m["path"], 0)
+        else:
+            m["idx"] = fpga.create_sparse_handle_from_csr(m["rp"], m["ci"], m["va"], m["rows"], m["cols"])
+        assert m["idx"] >= 0, f"{m['name']}: arena full"
+    fpga.load_matrices()
+    t_prep = time.time() - t0
+    for m in mats:
+        info = fpga.matrix_info(m["idx"])
+        m.update(rows=info["rows"], cols=info["cols"], nnz=info["nnz"], n_slices=info["n_slices"],
+                 device_bytes=info["device_bytes"], prep_seconds=info["prep_seconds"], n_split=info["n_split_rows"])
+        g = torch.Generator(device="cpu").manual_seed(1234 + m["idx"])
+        m["x"] = torch.rand(m["cols"], generator=g, dtype=torch.float32).to(dev)
+        m["b"] = torch.rand(m["rows"], generator=g, dtype=torch.float32).to(dev)
+        m["y"] = torch.zeros(m["rows"], dtype=torch.float32, device=dev)
+
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    if world > 1:
+        from hispmv_amd.dist import BoundaryExchange
+        exch = BoundaryExchange(len(mats), dev)
+
+    def step():
+        for m in mats:
+            fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
+        if world > 1:
+            exch.run(mats, ALPHA)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    t_wall = time.perf_counter() - t_start
+    t_dev = ev0.elapsed_time(ev1) * 1e-3          # HIP events on the launch stream
+    if world > 1:
+        tt = torch.tensor([t_wall, t_dev], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_wall, t_dev = float(tt[0]), float(tt[1])
+
+    # per-matrix table (outside the timed region): events around `reps` launches of one matrix; the
+    # other matrices are touched in between so that each measurement starts from a cold Infinity Cache
+    table = []
+    if rank == 0:
+        big = max(mats, key=lambda q: q["device_bytes"])
+        for m in mats:
+            ts = []
+            for _ in range(max(1, args.per_matrix_reps)):
+                if m is not big or len(mats) == 1:
+                    fpga.spmv_device(big["idx"], big["x"].data_ptr(), big["b"].data_ptr(), big["y"].data_ptr(), ALPHA, BETA, sptr)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
+                b.record(stream)
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e-3)
+            t = float(np.median(ts))
+            ab = M.algorithmic_bytes(m["rows"], m["cols"], m["nnz"])
+            table.append(dict(name=m["name"], source=m["source"], rows=m["rows"], nnz=m["nnz"], us=round(t * 1e6, 2),
+                              gflops=round(M.flops(m["rows"], m["nnz"]) / t / 1e9, 2), alg_gbs=round(ab / t / 1e9, 1),
+                              pct_hbm_peak=round(100 * ab / t / 1e9 / HBM_PEAK_GBS, 2), slices=m["n_slices"],
+                              split_rows=m["n_split"], prep_s=round(m["prep_seconds"], 3)))
+
+    flops_step = sum(M.flops(m["rows"], m["nnz"]) for m in mats)
+    bytes_step = sum(M.algorithmic_bytes(m["rows"], m["cols"], m["nnz"]) for m in mats)
+    if rank == 0:
+        total_flops = flops_step * world * args.steps
+        total_bytes = bytes_step * world * args.steps
+        value = total_flops / t_wall / 1e9
+        achieved = bytes_step * args.steps / t_dev / 1e9          # per GPU, device time
+        launches = len(mats) * args.steps
+        geo = math.exp(sum(math.log(r["gflops"]) for r in table) / len(table)) if table else None
+        out = {
+            "metric": "SpMV GFLOP/s, SuiteSparse set (20 matrices), fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
+            "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: full get_tb_matrices.py SuiteSparse set, one SpMV per matrix per step"
+                                   + (f", scaled {world}x in rows and nnz-split over {world} GPUs" if world > 1 else ""),
+                       "matrices": len(mats), "nnz_per_step_per_gpu": int(sum(m["nnz"] for m in mats)),
+                       "sources": sorted(set(m["source"].split(":")[0] for m in mats)),
+                       "alpha": ALPHA, "beta": BETA, "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
+            "hbm_gbs_algorithmic": round(total_bytes / t_wall / 1e9, 1),
+            "hbm_pct_of_peak": round(100 * total_bytes / t_wall / 1e9 / (HBM_PEAK_GBS * world), 2),
+            "geomean_gflops_per_matrix": None if geo is None else round(geo, 2),
+            "roofline": {"bound": "hbm", "kernel": "spmv_slices_kernel (+ carry fix-up launches)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch_avg": int(bytes_step / len(mats)),
+                         "avg_launch_us": round(t_dev / launches * 1e6, 3),
+                         "note": "achieved = sum over the set of (8*nnz+16*rows+4) B / HIP-event time of the timed region on the launch stream"},
+            "host": {"gen_s": round(t_gen, 1), "prep_upload_s": round(t_prep, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mats)
+        else:
+            out["cpu_baseline"] = None
+        if args.details:
+            Path(args.details).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.details).write_text(json.dumps({"summary": out, "per_matrix": table}, indent=1) + "\n")
+        print(json.dumps(out), flush=True)
+    fpga.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

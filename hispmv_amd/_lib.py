@@ -74,6 +74,21 @@ SIGNATURES = {
 }
 
 
+def _bind_single_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, same as /opt/rocm's) and load it by file name, so a process that loads both
+    copies ends up with two runtimes and the second one sees no GPU.  When torch is installed we
+    therefore bind to ITS copy first (the loader then resolves our NEEDED libamdhip64.so.7 to it);
+    otherwise the system ROCm runtime is used through our RUNPATH."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def _load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise ImportError(
@@ -81,6 +96,7 @@ def _load() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C hispmv_amd/csrc`). "
             "There is no CPU fallback."
         )
+    _bind_single_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol

@@ -1,0 +1,143 @@
+"""Multi-GPU SpMV: nnz-balanced split of the CSR element range over the ranks of one node, x
+replicated, and the exchange of the partial sums of rows cut by a rank boundary -- the reference's
+"shared row" idea (rows split over PEs and merged by the reduction network, spmv-helper.cpp:265-347,
+base_functions.cpp:356-437) one level up, over RCCL/xGMI.  The reference itself is single-device
+(no collectives anywhere), so this module has no reference counterpart.
+
+Only the cut rows travel: one all_gather of `n_matrices` floats per rank per step.  y is never
+all-reduced (a ring all-reduce of the largest y would cost more than the whole 1-GPU SpMV).
+
+Ownership rule (same as between wavefront slices): a row belongs to the rank that holds its LAST
+element; that rank adds beta*bias.  Ranks holding an earlier part compute alpha*partial only (their
+local bias entry for that row is zero) and publish it as their "tail".
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    elem_begin: int        # global element range [begin, end) of this rank
+    elem_end: int
+    row_begin: int         # global index of local row 0
+    n_rows: int            # local rows (first/last may be partial)
+    row_ptr: np.ndarray    # int32 [n_rows+1], local
+    col_idx: np.ndarray    # int32, global column ids (x is replicated)
+    values: np.ndarray
+    head_open: bool        # local row 0 continues a row begun on an earlier rank
+    tail_open: bool        # last local row continues on a later rank (this rank does not own it)
+
+    def local_bias(self, bias: np.ndarray) -> np.ndarray:
+        """bias restricted to the local rows, zeroed where this rank is not the owner."""
+        b = np.array(bias[self.row_begin:self.row_begin + self.n_rows], dtype=np.float32, copy=True)
+        if self.tail_open and self.n_rows:
+            b[-1] = 0.0
+        return b
+
+
+def split_points(n_elems: int, world: int) -> np.ndarray:
+    """Equal cut of [0, n_elems) into `world` ranges (the first ranges take the remainder)."""
+    base, rem = divmod(int(n_elems), world)
+    sizes = np.full(world, base, dtype=np.int64)
+    sizes[:rem] += 1
+    return np.concatenate([[0], np.cumsum(sizes)])
+
+
+def shard_csr(row_ptr, col_idx, values, world: int, rank: int) -> Shard:
+    """The rank's share of a global CSR matrix.  As in the slice stream, every row counts at least one
+    element (an empty row counts one filler), and the element sequence is cut into `world` equal ranges;
+    a cut may fall inside a row.  The local CSR keeps global column ids (x is replicated)."""
+    rp = np.asarray(row_ptr, dtype=np.int64)
+    rows = rp.size - 1
+    lens = np.diff(rp)
+    eoff = np.concatenate([[0], np.cumsum(np.maximum(lens, 1))])          # element offsets incl. fillers
+    cuts = split_points(int(eoff[-1]), world)
+    b, e = int(cuts[rank]), int(cuts[rank + 1])
+    if e == b:
+        return Shard(rank, world, b, e, 0, 0, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), False, False)
+    r0 = int(np.searchsorted(eoff[1:], b, side="right"))                  # first row ending after b
+    r1 = int(np.searchsorted(eoff[:-1], e, side="left"))                  # one past the last row starting before e
+    # real (non-filler) elements of local row i: global rows r0+i, clipped to the element range
+    lo = np.clip(b - eoff[r0:r1], 0, None)                               # elements of the row that lie before b
+    hi = np.clip(eoff[r0 + 1:r1 + 1] - e, 0, None)                       # ... after e
+    real = lens[r0:r1]
+    k0 = rp[r0:r1] + np.minimum(lo, real)
+    k1 = rp[r0:r1] + np.maximum(np.minimum(real, np.maximum(lens[r0:r1], 1) - hi), np.minimum(lo, real))
+    k1 = np.where(real == 0, k0, k1)
+    cnt = k1 - k0
+    loc = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    if cnt.sum():
+        idx = np.concatenate([np.arange(s, t) for s, t in zip(k0, k1) if t > s])
+    else:
+        idx = np.zeros(0, dtype=np.int64)
+    return Shard(rank, world, b, e, r0, r1 - r0, loc, np.asarray(col_idx)[idx].astype(np.int32),
+                 np.asarray(values)[idx].astype(np.float32), bool(eoff[r0] < b), bool(eoff[r1] > e))
+
+
+def chain_weights(flags: np.ndarray, rank: int) -> np.ndarray:
+    """flags[world, 3] = (head_open, tail_open, single_row) of one matrix on every rank.  Returns
+    w[world] in {0,1}: the ranks whose tails are parts of this rank's first row -- rank-1 if its tail is
+    open, and further down while the rank in between holds nothing but a piece of that same row."""
+    w = np.zeros(flags.shape[0], dtype=np.float32)
+    if not flags[rank, 0]:
+        return w
+    j = rank - 1
+    while j >= 0 and flags[j, 1]:
+        w[j] = 1.0
+        if not (flags[j, 0] and flags[j, 2]):
+            break
+        j -= 1
+    return w
+
+
+class BoundaryExchange:
+    """Per-step exchange on the device.  `mats` is the list bench.py / the caller keeps: each entry has
+    a device tensor "y" (local rows) and optionally "shard" (a Shard); entries without a shard are
+    row-aligned blocks (nothing is cut) and contribute zeros -- the collective still runs, it is the
+    path's exchange step."""
+
+    def __init__(self, n_mats: int, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device = device
+        self.n = n_mats
+        self.send = torch.zeros(n_mats, dtype=torch.float32, device=device)
+        self.recv = torch.zeros(self.world * n_mats, dtype=torch.float32, device=device)
+        self.ready = False
+
+    def _setup(self, mats):
+        torch, dist = self.torch, self.dist
+        flags = np.zeros((self.n, 3), dtype=np.float32)
+        for i, m in enumerate(mats):
+            sh = m.get("shard")
+            if sh is not None:
+                flags[i] = (sh.head_open, sh.tail_open, sh.n_rows == 1)
+        f = torch.from_numpy(flags).to(self.device)
+        allf = torch.zeros((self.world,) + tuple(f.shape), dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(allf, f)
+        allf = allf.cpu().numpy()                                    # [world, n, 3]
+        w = np.stack([chain_weights(allf[:, i, :], self.rank) for i in range(self.n)])   # [n, world]
+        self.weights = torch.from_numpy(w).to(self.device)
+        self.tail_mask = torch.from_numpy(flags[:, 1].copy()).to(self.device)
+        self.head_mask = torch.from_numpy(flags[:, 0].copy()).to(self.device)
+        self.ready = True
+
+    def run(self, mats, alpha: float) -> None:
+        torch, dist = self.torch, self.dist
+        if not self.ready:
+            self._setup(mats)
+        # tails: y_local[-1] of the rows this rank does not own (alpha*partial, bias masked out)
+        last = torch.stack([m["y"][-1] for m in mats])
+        torch.mul(last, self.tail_mask, out=self.send)
+        dist.all_gather_into_tensor(self.recv, self.send)
+        incoming = (self.recv.view(self.world, self.n).t() * self.weights).sum(dim=1) * self.head_mask
+        for i, m in enumerate(mats):
+            if m.get("shard") is not None and m["shard"].head_open:
+                m["y"][0] += incoming[i]
