@@ -151,14 +151,18 @@ def main():
     for m in mats:
         info = fpga.matrix_info(m["idx"])
         m.update(rows=info["rows"], cols=info["cols"], nnz=info["nnz"], n_slices=info["n_slices"],
-                 device_bytes=info["device_bytes"], prep_seconds=info["prep_seconds"], n_split=info["n_split_rows"])
+                 device_bytes=info["device_bytes"], prep_seconds=info["prep_seconds"], n_split=info["n_split_rows"],
+                 plan=f'{info["block_threads"]}t/{info["group_slices"]}s/{info["lds_bytes"] // 1024}KiB')
         g = torch.Generator(device="cpu").manual_seed(1234 + m["idx"])
         m["x"] = torch.rand(m["cols"], generator=g, dtype=torch.float32).to(dev)
         m["b"] = torch.rand(m["rows"], generator=g, dtype=torch.float32).to(dev)
         m["y"] = torch.zeros(m["rows"], dtype=torch.float32, device=dev)
 
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-default) HIP stream: every launch, event and collective of the timed region is on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
+    assert sptr != 0
     if world > 1:
         from hispmv_amd.dist import BoundaryExchange
         exch = BoundaryExchange(len(mats), dev)
@@ -212,7 +216,7 @@ def main():
             table.append(dict(name=m["name"], source=m["source"], rows=m["rows"], nnz=m["nnz"], us=round(t * 1e6, 2),
                               gflops=round(M.flops(m["rows"], m["nnz"]) / t / 1e9, 2), alg_gbs=round(ab / t / 1e9, 1),
                               pct_hbm_peak=round(100 * ab / t / 1e9 / HBM_PEAK_GBS, 2), slices=m["n_slices"],
-                              split_rows=m["n_split"], prep_s=round(m["prep_seconds"], 3)))
+                              split_rows=m["n_split"], prep_s=round(m["prep_seconds"], 3), plan=m["plan"]))
 
     flops_step = sum(M.flops(m["rows"], m["nnz"]) for m in mats)
     bytes_step = sum(M.algorithmic_bytes(m["rows"], m["cols"], m["nnz"]) for m in mats)

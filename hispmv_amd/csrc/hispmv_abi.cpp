@@ -38,6 +38,7 @@ struct Matrix {
     std::vector<FixEntry> fix_short, fix_long;
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0;
+    int plan_threads = 0, plan_group = 0, plan_lds = 0;
     // device side
     SpmvDeviceMatrix dev;
     float* d_dense = nullptr;
@@ -60,6 +61,8 @@ struct hispmv_ctx {
     int64_t arena_budget = 0, arena_used = 0;
     float *d_x = nullptr, *d_bias = nullptr, *d_y = nullptr;
     int64_t cap_x = 0, cap_bias = 0, cap_y = 0;
+    int* d_err = nullptr;        // set by a kernel whose bounded carry wait expired
+    bool use_lookback = true;    // HISPMV_CARRY=fixup selects the two-launch (fix-up kernel) variant
 };
 
 struct hispmv_prep {
@@ -87,7 +90,71 @@ int hip_fail(hispmv_ctx* c, hipError_t e, const char* what) {
 
 int64_t sparse_device_bytes(const SliceStream& st) {
     return (int64_t)st.words.size() * 8 + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
-           (int64_t)st.n_slices * 4;
+           (int64_t)st.n_slices * 12 + 8;
+}
+
+// A bounded in-kernel wait that expired leaves 1 in the context's error word.
+int check_device_error(hispmv_ctx* c) {
+    int flag = 0;
+    HIP_TRY(c, hipMemcpy(&flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        (void)hipMemset(c->d_err, 0, sizeof(int));
+        return fail(c, HISPMV_EDEVICE, "carry hand-off between slices timed out (lost or overlapping launch on one handle)");
+    }
+    return HISPMV_OK;
+}
+
+// Launch geometry of a sparse matrix: how many slices one workgroup owns, how many wavefronts it
+// has, and how much LDS holds its x window.  The MI355X analogue of the reference's per-matrix
+// configuration choice (automation_tool/src/dse.py:23-95 picks channel counts per matrix; here the
+// choice is the x-window policy): small windows -> many small workgroups per CU; large windows ->
+// one 16-wave workgroup per CU; windows that do not fit 160 KiB -> that group gathers x through L2.
+struct GroupPlan {
+    int block_threads = 256, group_slices = 8, lds_floats = 0;
+    std::vector<int2> groups;
+};
+
+GroupPlan plan_groups(const std::vector<SliceHdr>& hdr) {
+    const int64_t n = (int64_t)hdr.size();
+    struct Cfg { int threads, slices, cap; };
+    const Cfg cfgs[] = {{256, 8, 10 * 1024}, {512, 16, 20 * 1024}, {1024, 32, kMaxLdsFloats}};
+    GroupPlan best;
+    double best_frac = -1.0;
+    for (const Cfg& c : cfgs) {
+        int G = c.slices;
+        if (n / G < 1024 && G > 4) G /= 2;               // small matrices: more, smaller workgroups
+        if (n / G < 512 && G > 4) G /= 2;
+        const int64_t ng = (n + G - 1) / G;
+        std::vector<int2> groups((size_t)ng);
+        int64_t ok = 0;
+        int max_ok = 0;
+        for (int64_t g = 0; g < ng; ++g) {
+            int lo = INT32_MAX, hi = 0;
+            for (int64_t s = g * G; s < std::min<int64_t>(n, (g + 1) * G); ++s) {
+                lo = std::min(lo, hdr[s].x_base);
+                hi = std::max(hi, hdr[s].x_base + hdr[s].x_span);
+            }
+            lo &= ~3;                                      // 16-byte aligned window base
+            groups[g] = int2{lo, hi - lo};
+            if (hi - lo <= c.cap) { ok++; max_ok = std::max(max_ok, hi - lo); }
+        }
+        const double frac = ng ? (double)ok / (double)ng : 0.0;
+        if (frac > best_frac + 0.05 || best_frac < 0) {
+            best_frac = frac;
+            best.block_threads = c.threads; best.group_slices = G;
+            best.lds_floats = (max_ok + 3) & ~3;
+            best.groups = std::move(groups);
+        }
+        if (frac >= 0.9) break;
+    }
+    if (best_frac < 0.5) {   // mostly scattered columns: plain L2 gathers, small workgroups
+        GroupPlan g;
+        g.block_threads = 256; g.group_slices = (n / 8 < 1024) ? 4 : 8; g.lds_floats = 0;
+        const int64_t ng = (n + g.group_slices - 1) / g.group_slices;
+        g.groups.assign((size_t)std::max<int64_t>(ng, 1), int2{0, 0});
+        return g;
+    }
+    return best;
 }
 
 void free_matrix_device(Matrix& m) {
@@ -173,6 +240,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, HISPMV_EDEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     if ((e = hipSetDevice(device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+    if ((e = prepare_spmv_kernels()) != hipSuccess) return hip_fail(nullptr, e, "hipFuncSetAttribute(max dynamic LDS)");
 
     auto c = std::make_unique<hispmv_ctx>();
     c->device = device_id;
@@ -182,6 +250,9 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_ARENA_BYTES")) { long long v = std::atoll(env); if (v > 0) c->arena_budget = v; }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(nullptr, e, "hipStreamCreate");
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return hip_fail(nullptr, e, "hipEventCreate");
+    if ((e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(int))) != hipSuccess)
+        return hip_fail(nullptr, e, "hipMalloc(err flag)");
+    if (const char* env = std::getenv("HISPMV_CARRY")) c->use_lookback = std::strcmp(env, "fixup") != 0;
     *out = c.release();
     return HISPMV_OK;
 }
@@ -194,6 +265,7 @@ HISPMV_API void hispmv_destroy(hispmv_ctx* c) {
     if (c->d_x) (void)hipFree(c->d_x);
     if (c->d_bias) (void)hipFree(c->d_bias);
     if (c->d_y) (void)hipFree(c->d_y);
+    if (c->d_err) (void)hipFree(c->d_err);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -290,12 +362,16 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         Matrix& m = *mp;
         if (m.loaded) continue;
         int rc;
+        GroupPlan plan;   // must outlive the asynchronous upload below
         if (m.dense) {
             const float* d = nullptr;
             if ((rc = upload(c, m, m.dense_host.data(), m.dense_host.size(), &d)) != HISPMV_OK) return rc;
             m.d_dense = const_cast<float*>(d);
         } else {
             const uint64_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
+            const int2* dg = nullptr;
+            plan = plan_groups(m.st.hdr);
+            if ((rc = upload(c, m, plan.groups.data(), plan.groups.size(), &dg)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, m.st.words.data(), m.st.words.size(), &dw)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, m.st.hdr.data(), m.st.hdr.size(), &dh)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, m.fix_short.data(), m.fix_short.size(), &fs)) != HISPMV_OK) return rc;
@@ -307,6 +383,21 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             m.dev.words = dw; m.dev.hdr = (const int4*)dh;
             m.dev.fix_short = (const int4*)fs; m.dev.fix_long = (const int4*)fl;
             m.dev.carry = (float*)carry;
+            {   // carry granules {value, launch tag} and the group ticket of the single-launch variant
+                void *gran = nullptr, *ticket = nullptr;
+                const size_t gb = (size_t)std::max<int64_t>(m.n_slices, 1) * sizeof(unsigned long long);
+                HIP_TRY(c, hipMalloc(&gran, gb));
+                m.allocs.push_back(gran);
+                HIP_TRY(c, hipMemsetAsync(gran, 0, gb, c->stream));
+                HIP_TRY(c, hipMalloc(&ticket, sizeof(unsigned long long)));
+                m.allocs.push_back(ticket);
+                HIP_TRY(c, hipMemsetAsync(ticket, 0, sizeof(unsigned long long), c->stream));
+                m.dev.gran = (unsigned long long*)gran; m.dev.ticket = (unsigned long long*)ticket;
+                m.dev.err = c->d_err; m.dev.lookback = c->use_lookback; m.dev.launches = 0;
+            }
+            m.dev.groups = dg; m.dev.n_groups = (int64_t)((m.n_slices + plan.group_slices - 1) / plan.group_slices);
+            m.dev.group_slices = plan.group_slices; m.dev.block_threads = plan.block_threads; m.dev.lds_floats = plan.lds_floats;
+            m.plan_threads = plan.block_threads; m.plan_group = plan.group_slices; m.plan_lds = plan.lds_floats;
             m.dev.n_slices = m.n_slices;
             m.dev.n_fix_short = (int32_t)m.fix_short.size(); m.dev.n_fix_long = (int32_t)m.fix_long.size();
             m.dev.rows = m.rows; m.dev.cols = m.cols;
@@ -344,7 +435,7 @@ static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t nu
     HIP_TRY(c, hipMemcpyAsync(y, c->d_y, (size_t)m.rows * num_vecs * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1) != hipSuccess) c->last_ms = -1.0f;
-    return HISPMV_OK;
+    return check_device_error(c);
 }
 
 HISPMV_API int hispmv_run_kernel(hispmv_ctx* c, const float* x, const float* bias, float* y, float alpha, float beta) {
@@ -385,7 +476,7 @@ HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
     if (!c) return HISPMV_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return HISPMV_OK;
+    return check_device_error(c);
 }
 
 HISPMV_API float hispmv_last_kernel_ms(hispmv_ctx* c) { return c ? c->last_ms : -1.0f; }
@@ -415,6 +506,7 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->rows = m.rows; out->cols = m.cols; out->nnz = m.nnz; out->is_dense = m.dense; out->loaded = m.loaded;
     out->n_slices = m.n_slices; out->n_elems = m.n_elems; out->n_split_rows = m.n_split;
     out->device_bytes = m.device_bytes; out->prep_seconds = m.prep_seconds;
+    out->block_threads = m.plan_threads; out->group_slices = m.plan_group; out->lds_bytes = m.plan_lds * 4;
     return HISPMV_OK;
 }
 

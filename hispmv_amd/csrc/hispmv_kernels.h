@@ -11,17 +11,40 @@ struct SpmvDeviceMatrix {
     const int4* hdr = nullptr;          // n_slices x {row_base, chain_len, x_base, x_span}
     const int4* fix_short = nullptr;    // {row, first_slice, len, 0}, len <= kFixShortMax
     const int4* fix_long = nullptr;     // same, len > kFixShortMax
+    const int2* groups = nullptr;       // n_groups x {x_base (multiple of 4), x_span}: the x window of a workgroup
     float* carry = nullptr;             // n_slices: partial sum each slice hands to the next
+    int64_t n_groups = 0;
+    int32_t group_slices = 8;           // slices per workgroup
+    int32_t block_threads = 256;        // workgroup size (64 * wavefronts)
+    int32_t lds_floats = 0;             // dynamic LDS (floats) for the x window; 0 = gather x from L2
+    // single-launch carry hand-off between slices (look-back); when false the fix-up kernels run instead
+    bool lookback = true;
+    unsigned long long* gran = nullptr;     // n_slices x {fp32 carry, launch tag}
+    unsigned long long* ticket = nullptr;   // group tickets, monotonic over launches
+    int* err = nullptr;                     // set to 1 if a bounded wait expired
+    unsigned long long launches = 0;        // launches so far (host side)
     int64_t n_slices = 0;
     int32_t n_fix_short = 0, n_fix_long = 0;
     int32_t rows = 0, cols = 0;
 };
 
+struct LookbackArgs {
+    unsigned long long* gran;
+    unsigned long long* ticket;
+    int* err;
+    unsigned long long ticket_base;
+    unsigned epoch;
+};
+
 constexpr int kFixShortMax = 32;
+constexpr int kMaxLdsFloats = 40 * 1024 - 256;   // 160 KiB LDS per CU minus a little slack
+
+// Once per process/device before the first launch (raises the dynamic-LDS limit of the slice kernels).
+hipError_t prepare_spmv_kernels();
 
 // y = alpha*A*x + beta*bias.  Two launches on `stream`: the slice kernel, then (if any row is
 // shared between slices) the carry fix-up.  Returns the first HIP error.
-hipError_t launch_spmv(const SpmvDeviceMatrix& m, const float* x, const float* bias, float* y,
+hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, float* y,
                        float alpha, float beta, hipStream_t stream);
 
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.

@@ -119,6 +119,10 @@ typedef struct hispmv_matrix_info {
     int64_t n_split_rows;   /* rows shared between slices (the analogue of the shared-row list) */
     int64_t device_bytes;   /* bytes this handle takes in the arena */
     double prep_seconds;    /* host preprocessing time ("Pre-processing Time") */
+    int32_t block_threads;  /* launch plan chosen at load time: workgroup size, */
+    int32_t group_slices;   /*   slices per workgroup, */
+    int32_t lds_bytes;      /*   LDS bytes of the x window (0 = x gathered through L2) */
+    int32_t reserved;
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);

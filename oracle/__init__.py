@@ -64,7 +64,7 @@ def _load():
     lib.refpack_tile_size.argtypes = [_p, C.c_int, C.c_int]
     lib.refpack_shared_rows.argtypes = [_p, C.c_int, C.c_int, _p, C.c_int]
     lib.refpack_emulate.argtypes = [_p, _p, _p, C.c_float, C.c_float, _p]
-    lib.emu_spmv.argtypes = [_p, _p, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int32]
+    lib.emu_spmv.argtypes = [_p, _p, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int32, C.c_int]
     lib.emu_gemv.argtypes = [_p, C.c_int32, C.c_int32, _p, _p, C.c_float, C.c_float, _p]
     return lib
 
@@ -260,14 +260,15 @@ class RefPack:
         return y
 
 
-def emu_spmv(words, hdr, fix, x, bias, alpha, beta, rows):
-    """CPU model of the product's slice kernel + fix-up on the product's own stream (slice_emu.inc)."""
+def emu_spmv(words, hdr, fix, x, bias, alpha, beta, rows, mode=1):
+    """CPU model of the product's slice kernel on the product's own stream (slice_emu.inc).
+    mode 1 = single launch with carry look-back (the default product path); 0 = fix-up kernels."""
     words = _c(words, np.uint64)
     hdr = _c(hdr, np.int32).reshape(-1, 4)
     fix = _c(fix, np.int32).reshape(-1, 4)
     xx, bb = _c(x, np.float32), _c(bias, np.float32)
     y = np.zeros(rows, dtype=np.float32)
-    lib.emu_spmv(_ptr(words), _ptr(hdr), _ptr(fix), hdr.shape[0], fix.shape[0], _ptr(xx), _ptr(bb), alpha, beta, _ptr(y), rows)
+    lib.emu_spmv(_ptr(words), _ptr(hdr), _ptr(fix), hdr.shape[0], fix.shape[0], _ptr(xx), _ptr(bb), alpha, beta, _ptr(y), rows, mode)
     return y
 
 

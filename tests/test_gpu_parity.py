@@ -67,6 +67,37 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
     assert info["nnz"] == g["ref_col_idx"].size and info["loaded"] == 1 and not info["is_dense"]
 
 
+@pytest.mark.parametrize("carry,mode", [("lookback", 1), ("fixup", 0)])
+def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypatch, carry, mode):
+    """Rows shared between slices: the single-launch look-back (default) and the two-launch fix-up
+    variant (HISPMV_CARRY=fixup) each reproduce their CPU model bit for bit, on a matrix with short
+    chains, a 100-slice chain and empty rows."""
+    from hispmv_amd.prep import prep_from_coo
+    monkeypatch.setenv("HISPMV_CARRY", carry)
+    rng = np.random.default_rng(3)
+    rows, cols, nnz = 20000, 15000, 400000
+    r = rng.integers(0, rows, nnz)
+    r[:100000] = 1234
+    r[r % 5 == 0] += 1
+    c = rng.integers(0, cols, nnz)
+    v = rng.random(nnz, dtype=np.float32) - 0.5
+    x = rng.random(cols, dtype=np.float32)
+    b = rng.random(rows, dtype=np.float32)
+    h = pyhispmv_mod.FpgaHandle(*HW)
+    idx = h.create_sparse_handle(r, c, v, rows, cols)
+    h.load_matrices()
+    h.select_matrix(idx)
+    P = prep_from_coo(r, c, v, rows, cols)
+    y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, ALPHA, BETA)
+    for _ in range(3):                      # repeated launches reuse the granules with a new launch tag
+        y = np.full(rows, np.nan, np.float32)
+        h.run_kernel(x, b, y, ALPHA, BETA)
+        assert bwd_err(y, y64, mag) < TOL
+        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, ALPHA, BETA, rows, mode)
+        assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
+    h.close()
+
+
 def test_general_test_call_sequence_scaled(fpga):
     """apps/general_test.py:22-113 with the same call order, dense 5000x1000 + 100 k random COO
     (duplicates included), checked with the script's own np.allclose(rtol=1e-3) and the 1e-5 gate."""

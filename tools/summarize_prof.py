@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into the small
+tracked files profiles/<tag>_kernel_stats.csv and profiles/<tag>_summary.md.
+
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so the read side is
+doubled; WRITE_SIZE is exact for dword-per-lane stores.  Collected in separate --pmc passes."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = Path("gpurun_out") / f"prof_{tag}"
+dst = Path("profiles")
+dst.mkdir(exist_ok=True)
+
+
+def first(pattern):
+    g = sorted(glob.glob(str(src / pattern), recursive=True))
+    return g[0] if g else None
+
+
+out = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `tools/profile_round.sh " + tag + "` (bench.py --steps 5 --warmup 1, 20-matrix set)", ""]
+stats = first("trace/**/*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(dst / f"{tag}_kernel_stats.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    out += ["## Kernel time (`--kernel-trace --stats`)", "", "| kernel | calls | avg us | total ms | % |", "|---|---:|---:|---:|---:|"]
+    for r in rows[:8]:
+        out.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.1f} |")
+    out.append("")
+
+
+def pmc(kind, counter):
+    f = first(f"{kind}/**/*counter_collection.csv")
+    if not f:
+        return None
+    tot = defaultdict(float)
+    calls = defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") == counter:
+            name = r["Kernel_Name"]
+            tot[name] += float(r["Counter_Value"])
+            calls[name] += 1
+    return tot, calls
+
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+traffic = {}
+if fetch or write:
+    out += ["## HBM traffic (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes)", "",
+            "| kernel | launches | FETCH_SIZE KiB/launch (raw) | read MB/launch (x2 gfx950 correction) | WRITE MB/launch |", "|---|---:|---:|---:|---:|"]
+    names = set((fetch[0] if fetch else {}).keys()) | set((write[0] if write else {}).keys())
+    for n in sorted(names, key=lambda k: -(fetch[0].get(k, 0) if fetch else 0)):
+        if "hispmv" not in n:
+            continue
+        fk = fetch[0].get(n, 0) / max(1, fetch[1].get(n, 1)) if fetch else 0
+        wk = write[0].get(n, 0) / max(1, write[1].get(n, 1)) if write else 0
+        traffic[n[:60]] = {"launches": fetch[1].get(n, 0) if fetch else 0, "read_bytes_per_launch": fk * 1024 * 2, "write_bytes_per_launch": wk * 1024}
+        out.append(f"| `{n[:60]}` | {fetch[1].get(n, 0) if fetch else 0} | {fk:.0f} | {fk*1024*2/1e6:.2f} | {wk*1024/1e6:.2f} |")
+    out.append("")
+(dst / f"{tag}_summary.md").write_text("\n".join(out) + "\n")
+(dst / f"{tag}_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+print("\n".join(out))
