@@ -62,7 +62,7 @@ struct hispmv_ctx {
     float *d_x = nullptr, *d_bias = nullptr, *d_y = nullptr;
     int64_t cap_x = 0, cap_bias = 0, cap_y = 0;
     int* d_err = nullptr;        // set by a kernel whose bounded carry wait expired
-    bool use_lookback = true;    // HISPMV_CARRY=fixup selects the two-launch (fix-up kernel) variant
+    bool use_lookback = false;   // HISPMV_CARRY=lookback selects the single-launch carry look-back variant
 };
 
 struct hispmv_prep {
@@ -252,7 +252,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return hip_fail(nullptr, e, "hipEventCreate");
     if ((e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(int))) != hipSuccess)
         return hip_fail(nullptr, e, "hipMalloc(err flag)");
-    if (const char* env = std::getenv("HISPMV_CARRY")) c->use_lookback = std::strcmp(env, "fixup") != 0;
+    if (const char* env = std::getenv("HISPMV_CARRY")) c->use_lookback = std::strcmp(env, "lookback") == 0;
     *out = c.release();
     return HISPMV_OK;
 }

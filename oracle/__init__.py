@@ -260,9 +260,9 @@ class RefPack:
         return y
 
 
-def emu_spmv(words, hdr, fix, x, bias, alpha, beta, rows, mode=1):
+def emu_spmv(words, hdr, fix, x, bias, alpha, beta, rows, mode=0):
     """CPU model of the product's slice kernel on the product's own stream (slice_emu.inc).
-    mode 1 = single launch with carry look-back (the default product path); 0 = fix-up kernels."""
+    mode 0 = slice kernel + fix-up kernels (the default product path); 1 = single launch with carry look-back."""
     words = _c(words, np.uint64)
     hdr = _c(hdr, np.int32).reshape(-1, 4)
     fix = _c(fix, np.int32).reshape(-1, 4)

@@ -61,7 +61,7 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
     assert pl < 1e-5
     # the CPU model of the wavefront performs the same fp32 operations in the same order
     P = prep_from_mtx(GOLDEN / f"{name}.mtx", 1)
-    ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, rows)
+    ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, rows, 0)   # default product path: fix-up variant
     assert np.array_equal(y.view(np.uint32), ye.view(np.uint32)), "GPU result differs bitwise from the wavefront model"
     info = fpga.matrix_info(idx)
     assert info["nnz"] == g["ref_col_idx"].size and info["loaded"] == 1 and not info["is_dense"]
@@ -69,9 +69,9 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
 
 @pytest.mark.parametrize("carry,mode", [("lookback", 1), ("fixup", 0)])
 def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypatch, carry, mode):
-    """Rows shared between slices: the single-launch look-back (default) and the two-launch fix-up
-    variant (HISPMV_CARRY=fixup) each reproduce their CPU model bit for bit, on a matrix with short
-    chains, a 100-slice chain and empty rows."""
+    """Rows shared between slices: the two-launch fix-up variant (default) and the single-launch
+    look-back (HISPMV_CARRY=lookback) each reproduce their CPU model bit for bit, on a matrix with
+    short chains, a 100-slice chain and empty rows."""
     from hispmv_amd.prep import prep_from_coo
     monkeypatch.setenv("HISPMV_CARRY", carry)
     rng = np.random.default_rng(3)
