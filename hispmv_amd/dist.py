@@ -96,10 +96,11 @@ def chain_weights(flags: np.ndarray, rank: int) -> np.ndarray:
 
 
 class BoundaryExchange:
-    """Per-step exchange on the device.  `mats` is the list bench.py / the caller keeps: each entry has
-    a device tensor "y" (local rows) and optionally "shard" (a Shard); entries without a shard are
-    row-aligned blocks (nothing is cut) and contribute zeros -- the collective still runs, it is the
-    path's exchange step."""
+    """Per-step exchange of the cut rows.  `mats` is the list the caller keeps: each entry has a tensor
+    "y" (the rank's local rows, device or CPU) and optionally "shard" (a Shard); entries without a shard
+    are row-aligned blocks (nothing is cut) and contribute zeros -- the collective still runs, it is the
+    path's exchange step.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the
+    CPU tests)."""
 
     def __init__(self, n_mats: int, device):
         import torch
@@ -112,32 +113,43 @@ class BoundaryExchange:
         self.recv = torch.zeros(self.world * n_mats, dtype=torch.float32, device=device)
         self.ready = False
 
+    def _all_gather(self, out, inp):
+        if self.dist.get_backend() == "gloo":
+            parts = list(out.view(self.world, -1).unbind(0))
+            self.dist.all_gather(parts, inp.reshape(-1))
+        else:
+            self.dist.all_gather_into_tensor(out, inp)
+
     def _setup(self, mats):
-        torch, dist = self.torch, self.dist
+        torch = self.torch
         flags = np.zeros((self.n, 3), dtype=np.float32)
         for i, m in enumerate(mats):
             sh = m.get("shard")
             if sh is not None:
                 flags[i] = (sh.head_open, sh.tail_open, sh.n_rows == 1)
-        f = torch.from_numpy(flags).to(self.device)
-        allf = torch.zeros((self.world,) + tuple(f.shape), dtype=torch.float32, device=self.device)
-        dist.all_gather_into_tensor(allf, f)
-        allf = allf.cpu().numpy()                                    # [world, n, 3]
+        f = torch.from_numpy(flags.reshape(-1)).to(self.device)
+        allf = torch.zeros(self.world * f.numel(), dtype=torch.float32, device=self.device)
+        self._all_gather(allf, f)
+        allf = allf.cpu().numpy().reshape(self.world, self.n, 3)
         w = np.stack([chain_weights(allf[:, i, :], self.rank) for i in range(self.n)])   # [n, world]
         self.weights = torch.from_numpy(w).to(self.device)
         self.tail_mask = torch.from_numpy(flags[:, 1].copy()).to(self.device)
-        self.head_mask = torch.from_numpy(flags[:, 0].copy()).to(self.device)
+        self.heads = [i for i in range(self.n) if flags[i, 0]]
+        self.has_rows = [bool(m["y"].numel()) for m in mats]
+        self.zero = torch.zeros((), dtype=torch.float32, device=self.device)
         self.ready = True
 
-    def run(self, mats, alpha: float) -> None:
-        torch, dist = self.torch, self.dist
+    def run(self, mats, alpha: float = 1.0) -> None:
+        """After every rank's local SpMV of every matrix: publish the tails (y_local[-1] of rows this rank
+        does not own: alpha*partial, its bias entry was zeroed), gather them, add the chain into the owner's
+        first row."""
+        torch = self.torch
         if not self.ready:
             self._setup(mats)
-        # tails: y_local[-1] of the rows this rank does not own (alpha*partial, bias masked out)
-        last = torch.stack([m["y"][-1] for m in mats])
+        last = torch.stack([m["y"][-1] if ok else self.zero for m, ok in zip(mats, self.has_rows)])
         torch.mul(last, self.tail_mask, out=self.send)
-        dist.all_gather_into_tensor(self.recv, self.send)
-        incoming = (self.recv.view(self.world, self.n).t() * self.weights).sum(dim=1) * self.head_mask
-        for i, m in enumerate(mats):
-            if m.get("shard") is not None and m["shard"].head_open:
-                m["y"][0] += incoming[i]
+        self._all_gather(self.recv, self.send)
+        if self.heads:
+            incoming = (self.recv.view(self.world, self.n).t() * self.weights).sum(dim=1)
+            for i in self.heads:
+                mats[i]["y"][0] += incoming[i]

@@ -1,0 +1,118 @@
+"""Multi-GPU path on CPU: world_size 2 and 3 `gloo` process groups exercise the nnz-balanced sharding and
+the boundary exchange of hispmv_amd/dist.py.  The local SpMV of each rank is played by the oracle
+(checker), exactly where a GPU rank would call hispmv_spmv_device; ownership, tails and the chain of a
+row that passes through a whole rank are what is under test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from hispmv_amd.dist import BoundaryExchange, chain_weights, shard_csr, split_points
+from util import bwd_err
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def make_matrices():
+    rng = np.random.default_rng(21)
+    mats = []
+    for k, (rows, cols, nnz, heavy) in enumerate([(300, 200, 6000, 0), (50, 400, 9000, 7000), (4000, 50, 9000, 0), (64, 64, 0, 0)]):
+        r = rng.integers(0, rows, nnz)
+        if heavy:
+            r[:heavy] = 20                   # one row holding most of the matrix: spans several ranks
+        if k == 2:
+            r = r - (r % 3 == 1)             # many empty rows
+        c = rng.integers(0, cols, nnz)
+        v = rng.random(nnz).astype(np.float32) - 0.5
+        order = np.lexsort((c, r))
+        rp = np.zeros(rows + 1, np.int64)
+        np.add.at(rp, r + 1, 1)
+        mats.append(dict(rows=rows, cols=cols, rp=np.cumsum(rp).astype(np.int32), ci=c[order].astype(np.int32), va=v[order],
+                         x=rng.random(cols).astype(np.float32), b=rng.random(rows).astype(np.float32)))
+    return mats
+
+
+def _worker(rank, world, port, alpha, beta, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mats = make_matrices()
+    local = []
+    for m in mats:
+        sh = shard_csr(m["rp"], m["ci"], m["va"], world, rank)
+        y0 = sh.local_bias(m["b"])
+        y = oracle.cpu_spmv(sh.row_ptr, sh.col_idx, sh.values, m["x"], y0, alpha, beta, 1) if sh.n_rows else np.zeros(0, np.float32)
+        local.append(dict(y=torch.from_numpy(y.copy()), shard=sh))
+    ex = BoundaryExchange(len(mats), torch.device("cpu"))
+    for _ in range(2):                        # the second run must not double count (tails are re-read, heads re-added)
+        for ent, m in zip(local, mats):
+            sh = ent["shard"]
+            if sh.n_rows:
+                ent["y"].copy_(torch.from_numpy(oracle.cpu_spmv(sh.row_ptr, sh.col_idx, sh.values, m["x"], sh.local_bias(m["b"]), alpha, beta, 1)))
+        ex.run(local, alpha)
+    res = []
+    for ent in local:
+        sh = ent["shard"]
+        n_own = sh.n_rows - (1 if sh.tail_open else 0)
+        res.append((sh.row_begin, n_own, ent["y"][:n_own].numpy().copy(), sh.head_open, sh.tail_open))
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_nnz_sharded_spmv_with_boundary_exchange(world):
+    alpha, beta = 0.85, -2.06
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mats = make_matrices()
+    for i, m in enumerate(mats):
+        y = np.full(m["rows"], np.nan, np.float32)
+        cover = np.zeros(m["rows"], int)
+        for r in range(world):
+            row_begin, n_own, yl, _, _ = results[r][i]
+            y[row_begin:row_begin + n_own] = yl
+            cover[row_begin:row_begin + n_own] += 1
+        assert (cover == 1).all(), "every row has exactly one owner"
+        y64, mag = oracle.spmv_f64(m["rp"], m["ci"], m["va"], m["x"], m["b"], alpha, beta)
+        assert bwd_err(y, y64, mag) < 1e-5
+    if world == 3:   # the heavy row of matrix 1 passes through the middle rank
+        assert results[1][1][3] and results[1][1][4]
+
+
+def test_split_points_and_chain_weights():
+    assert split_points(10, 3).tolist() == [0, 4, 7, 10]
+    assert split_points(0, 2).tolist() == [0, 0, 0]
+    flags = np.array([[0, 1, 0], [1, 1, 1], [1, 1, 1], [1, 0, 0]], np.float32)     # one row over 4 ranks
+    assert chain_weights(flags, 3).tolist() == [1, 1, 1, 0]
+    assert chain_weights(flags, 0).tolist() == [0, 0, 0, 0]
+    flags = np.array([[0, 1, 0], [1, 1, 0], [1, 0, 0]], np.float32)                 # rank 1 holds more than that row
+    assert chain_weights(flags, 2).tolist() == [0, 1, 0]
+    assert chain_weights(flags, 1).tolist() == [1, 0, 0]
+
+
+def test_shards_cover_matrix_exactly():
+    m = make_matrices()[1]
+    for world in (1, 2, 5, 8):
+        tot = 0
+        for rank in range(world):
+            sh = shard_csr(m["rp"], m["ci"], m["va"], world, rank)
+            tot += sh.values.size
+            assert sh.row_ptr[-1] == sh.values.size == sh.col_idx.size
+        assert tot == m["va"].size
