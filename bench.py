@@ -152,7 +152,7 @@ def main():
         info = fpga.matrix_info(m["idx"])
         m.update(rows=info["rows"], cols=info["cols"], nnz=info["nnz"], n_slices=info["n_slices"],
                  device_bytes=info["device_bytes"], prep_seconds=info["prep_seconds"], n_split=info["n_split_rows"],
-                 plan=f'{info["block_threads"]}t/{info["group_slices"]}s/{info["lds_bytes"] // 1024}KiB')
+                 plan=f'{info["block_threads"]}t/{info["group_slices"]}s/{info["lds_bytes"] // 1024}KiB/{info["col_tiles"]}ct')
         g = torch.Generator(device="cpu").manual_seed(1234 + m["idx"])
         m["x"] = torch.rand(m["cols"], generator=g, dtype=torch.float32).to(dev)
         m["b"] = torch.rand(m["rows"], generator=g, dtype=torch.float32).to(dev)

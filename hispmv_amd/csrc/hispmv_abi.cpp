@@ -26,6 +26,12 @@ using namespace hispmv;
 
 namespace {
 
+// Launch geometry of one slice stream (see plan_groups below).
+struct GroupPlan {
+    int block_threads = 256, group_slices = 8, lds_floats = 0;
+    std::vector<int2> groups;
+};
+
 struct Matrix {
     bool dense = false;
     int32_t rows = 0, cols = 0;
@@ -33,14 +39,20 @@ struct Matrix {
     double prep_seconds = 0;
     int64_t device_bytes = 0;
     bool loaded = false;
-    // host side (released after upload)
-    SliceStream st;
-    std::vector<FixEntry> fix_short, fix_long;
+    // A sparse matrix is one slice stream, or -- when x is too large for an XCD's L2 and the columns
+    // are scattered -- one stream per COLUMN TILE (the reference's column tiling, tileAndPad
+    // spmv-helper.cpp:242-263, with L2 in the role of the BRAM x window): part 0 computes
+    // y = alpha*A0*x + beta*bias, part t > 0 accumulates y = alpha*At*x + 1*y.
+    struct Part {
+        SliceStream st;                            // host side (released after upload)
+        std::vector<FixEntry> fix_short, fix_long;
+        GroupPlan plan;
+        SpmvDeviceMatrix dev;                      // device side
+    };
+    std::vector<Part> parts;
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0;
     int plan_threads = 0, plan_group = 0, plan_lds = 0;
-    // device side
-    SpmvDeviceMatrix dev;
     float* d_dense = nullptr;
     std::vector<void*> allocs;
 };
@@ -61,8 +73,13 @@ struct hispmv_ctx {
     int64_t arena_budget = 0, arena_used = 0;
     float *d_x = nullptr, *d_bias = nullptr, *d_y = nullptr;
     int64_t cap_x = 0, cap_bias = 0, cap_y = 0;
+    int64_t col_tile_bytes = 4 << 20;   // x bytes per column tile for scattered matrices (HISPMV_COL_TILE_BYTES)
     int* d_err = nullptr;        // set by a kernel whose bounded carry wait expired
-    bool use_lookback = false;   // HISPMV_CARRY=lookback selects the single-launch carry look-back variant
+    // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
+    // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
+    // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.
+    int carry_mode = 2;          // 0 fixup, 1 lookback, 2 auto (HISPMV_CARRY)
+    int n_cus = 256;
 };
 
 struct hispmv_prep {
@@ -109,45 +126,63 @@ int check_device_error(hispmv_ctx* c) {
 // configuration choice (automation_tool/src/dse.py:23-95 picks channel counts per matrix; here the
 // choice is the x-window policy): small windows -> many small workgroups per CU; large windows ->
 // one 16-wave workgroup per CU; windows that do not fit 160 KiB -> that group gathers x through L2.
-struct GroupPlan {
-    int block_threads = 256, group_slices = 8, lds_floats = 0;
-    std::vector<int2> groups;
-};
+// Column window of the slices [s0, s1): {base aligned down to 4 floats, span}.
+static int2 window_of(const std::vector<SliceHdr>& hdr, int64_t s0, int64_t s1) {
+    int lo = INT32_MAX, hi = 0;
+    for (int64_t s = s0; s < s1; ++s) {
+        lo = std::min(lo, hdr[s].x_base);
+        hi = std::max(hi, hdr[s].x_base + hdr[s].x_span);
+    }
+    if (s1 <= s0) return int2{0, 0};
+    lo &= ~3;
+    return int2{lo, hi - lo};
+}
 
-GroupPlan plan_groups(const std::vector<SliceHdr>& hdr) {
+GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus) {
     const int64_t n = (int64_t)hdr.size();
-    struct Cfg { int threads, slices, cap; };
-    const Cfg cfgs[] = {{256, 8, 10 * 1024}, {512, 16, 20 * 1024}, {1024, 32, kMaxLdsFloats}};
+    // threads per workgroup, slices per workgroup (0 = one chunk per resident workgroup), LDS cap (floats),
+    // resident workgroups per CU at that cap
+    struct Cfg { int threads, slices, cap, per_cu; };
+    const Cfg cfgs[] = {
+        {256, 8, 10 * 1024, 4},            // small windows: many small workgroups
+        {512, 16, 20 * 1024, 2},
+        {512, 0, 20 * 1024 - 256, 2},      // persistent: 2 workgroups per CU, window staged once per workgroup
+        {512, 32, kMaxLdsFloats, 1},
+        {512, 0, kMaxLdsFloats, 1},        // persistent: 1 workgroup per CU
+    };
     GroupPlan best;
-    double best_frac = -1.0;
+    double best_cost = 1e300;
+    bool have = false;
     for (const Cfg& c : cfgs) {
-        int G = c.slices;
-        if (n / G < 1024 && G > 4) G /= 2;               // small matrices: more, smaller workgroups
-        if (n / G < 512 && G > 4) G /= 2;
+        int64_t G = c.slices;
+        if (G == 0) {
+            G = (n + (int64_t)n_cus * c.per_cu - 1) / ((int64_t)n_cus * c.per_cu);
+            if (G < 8) continue;                            // too little work to be worth a resident grid
+        } else {
+            if (n / G < 1024 && G > 4) G /= 2;              // small matrices: more, smaller workgroups
+            if (n / G < 512 && G > 4) G /= 2;
+        }
         const int64_t ng = (n + G - 1) / G;
         std::vector<int2> groups((size_t)ng);
-        int64_t ok = 0;
+        int64_t ok = 0, staged = 0;
         int max_ok = 0;
         for (int64_t g = 0; g < ng; ++g) {
-            int lo = INT32_MAX, hi = 0;
-            for (int64_t s = g * G; s < std::min<int64_t>(n, (g + 1) * G); ++s) {
-                lo = std::min(lo, hdr[s].x_base);
-                hi = std::max(hi, hdr[s].x_base + hdr[s].x_span);
-            }
-            lo &= ~3;                                      // 16-byte aligned window base
-            groups[g] = int2{lo, hi - lo};
-            if (hi - lo <= c.cap) { ok++; max_ok = std::max(max_ok, hi - lo); }
+            groups[g] = window_of(hdr, g * G, std::min<int64_t>(n, (g + 1) * G));
+            if (groups[g].y <= c.cap) { ok++; max_ok = std::max(max_ok, groups[g].y); staged += groups[g].y; }
         }
         const double frac = ng ? (double)ok / (double)ng : 0.0;
-        if (frac > best_frac + 0.05 || best_frac < 0) {
-            best_frac = frac;
-            best.block_threads = c.threads; best.group_slices = G;
+        if (frac < 0.9) continue;
+        // cost = x floats staged into LDS per stream element (lower is better); slight preference for more
+        // resident wavefronts
+        const double cost = (double)staged / (double)(n * kSliceElems) + 0.02 / (double)(c.per_cu * c.threads / 64);
+        if (cost < best_cost) {
+            best_cost = cost; have = true;
+            best.block_threads = c.threads; best.group_slices = (int)G;
             best.lds_floats = (max_ok + 3) & ~3;
             best.groups = std::move(groups);
         }
-        if (frac >= 0.9) break;
     }
-    if (best_frac < 0.5) {   // mostly scattered columns: plain L2 gathers, small workgroups
+    if (!have) {   // scattered columns: plain L2 gathers, small workgroups
         GroupPlan g;
         g.block_threads = 256; g.group_slices = (n / 8 < 1024) ? 4 : 8; g.lds_floats = 0;
         const int64_t ng = (n + g.group_slices - 1) / g.group_slices;
@@ -160,7 +195,7 @@ GroupPlan plan_groups(const std::vector<SliceHdr>& hdr) {
 void free_matrix_device(Matrix& m) {
     for (void* p : m.allocs) (void)hipFree(p);
     m.allocs.clear();
-    m.dev = SpmvDeviceMatrix{};
+    for (auto& p : m.parts) p.dev = SpmvDeviceMatrix{};
     m.d_dense = nullptr;
     m.loaded = false;
 }
@@ -175,17 +210,78 @@ int ensure_vec(hispmv_ctx* c, float** p, int64_t* cap, int64_t n) {
     return HISPMV_OK;
 }
 
+// Column range [c0, c1) of a CSR matrix as its own CSR (global column ids are kept: x is shared).
+Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
+    Csr t;
+    t.rows = m.rows; t.cols = m.cols;
+    t.row_ptr.assign((size_t)m.rows + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        t.row_ptr[(size_t)i + 1] = std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0);
+    }
+    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
+    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
+        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
+        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
+        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
+    }
+    return t;
+}
+
+// Width (in columns) of a column tile; 0 = no tiling.  Tiling applies only when the plan of the whole
+// matrix gathers x through L2 (no LDS window) and x exceeds `tile_bytes` (default 4 MiB = one XCD's
+// L2, i.e. tiles of 2-4 MiB; HISPMV_COL_TILE_BYTES overrides, 0 disables).
+int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
+    if (tile_bytes <= 0 || (int64_t)cols * 4 <= tile_bytes + tile_bytes / 2) return 0;
+    const int64_t tiles = ((int64_t)cols * 4 + tile_bytes - 1) / tile_bytes;
+    const int64_t w = (((int64_t)cols + tiles - 1) / tiles + 63) & ~63LL;     // equal tiles, 256-byte aligned
+    return (int32_t)w;
+}
+
+void finish_part(Matrix::Part& p, int n_cus) {
+    for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
+    p.plan = plan_groups(p.st.hdr, n_cus);
+}
+
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
 // "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).
 int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
     auto t0 = std::chrono::steady_clock::now();
     auto m = std::make_unique<Matrix>();
     m->rows = csr.rows; m->cols = csr.cols; m->nnz = csr.nnz();
-    m->st = build_stream(csr);
+    m->parts.emplace_back();
+    m->parts[0].st = build_stream(csr);
+    finish_part(m->parts[0], c->n_cus);
+    // Column tiling when the whole-matrix plan has to gather x through L2:
+    //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
+    //  * x larger than an XCD's L2: L2-sized tiles.
+    int32_t tw = 0;
+    if (m->parts[0].plan.lds_floats == 0) {
+        if (csr.cols <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0) tw = ((csr.cols + 1) / 2 + 63) & ~63;
+        else tw = column_tile_width(csr.cols, c->col_tile_bytes);
+    }
+    if (tw > 0) {
+        m->parts.clear();
+        for (int32_t c0 = 0; c0 < csr.cols; c0 += tw) {
+            m->parts.emplace_back();
+            m->parts.back().st = build_stream(column_tile(csr, c0, std::min<int64_t>((int64_t)c0 + tw, csr.cols)));
+            finish_part(m->parts.back(), c->n_cus);
+        }
+    }
     csr = Csr{};
-    for (const FixEntry& f : m->st.fix) (f.len <= kFixShortMax ? m->fix_short : m->fix_long).push_back(f);
-    m->n_slices = m->st.n_slices; m->n_elems = m->st.n_elems; m->n_split = (int64_t)m->st.fix.size();
-    m->device_bytes = sparse_device_bytes(m->st);
+    for (auto& p : m->parts) {
+        m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
+        m->device_bytes += sparse_device_bytes(p.st) + (int64_t)p.plan.groups.size() * 8;
+    }
+    m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
+    m->plan_lds = m->parts[0].plan.lds_floats;
     m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
     c->arena_used += m->device_bytes;
@@ -207,9 +303,17 @@ int upload(hispmv_ctx* c, Matrix& m, const T* host, size_t count, const T** dev_
 
 int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
                   float alpha, float beta, hipStream_t s) {
-    hipError_t e = m.dense ? launch_gemv(m.d_dense, m.rows, m.cols, d_x, d_bias, d_y, alpha, beta, s)
-                           : launch_spmv(m.dev, d_x, d_bias, d_y, alpha, beta, s);
-    if (e != hipSuccess) return hip_fail(c, e, m.dense ? "launch_gemv" : "launch_spmv");
+    if (m.dense) {
+        hipError_t e = launch_gemv(m.d_dense, m.rows, m.cols, d_x, d_bias, d_y, alpha, beta, s);
+        if (e != hipSuccess) return hip_fail(c, e, "launch_gemv");
+        return HISPMV_OK;
+    }
+    for (size_t t = 0; t < m.parts.size(); ++t) {
+        // column tile t > 0 accumulates on top of what the earlier tiles wrote: beta = 1, bias = y
+        hipError_t e = (t == 0) ? launch_spmv(m.parts[t].dev, d_x, d_bias, d_y, alpha, beta, s)
+                                : launch_spmv(m.parts[t].dev, d_x, d_y, d_y, alpha, 1.0f, s);
+        if (e != hipSuccess) return hip_fail(c, e, "launch_spmv");
+    }
     return HISPMV_OK;
 }
 
@@ -252,7 +356,10 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return hip_fail(nullptr, e, "hipEventCreate");
     if ((e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(int))) != hipSuccess)
         return hip_fail(nullptr, e, "hipMalloc(err flag)");
-    if (const char* env = std::getenv("HISPMV_CARRY")) c->use_lookback = std::strcmp(env, "lookback") == 0;
+    if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
+    if (const char* env = std::getenv("HISPMV_CARRY"))
+        c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : 2;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = c.release();
     return HISPMV_OK;
 }
@@ -362,49 +469,56 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         Matrix& m = *mp;
         if (m.loaded) continue;
         int rc;
-        GroupPlan plan;   // must outlive the asynchronous upload below
         if (m.dense) {
             const float* d = nullptr;
             if ((rc = upload(c, m, m.dense_host.data(), m.dense_host.size(), &d)) != HISPMV_OK) return rc;
             m.d_dense = const_cast<float*>(d);
         } else {
-            const uint64_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
-            const int2* dg = nullptr;
-            plan = plan_groups(m.st.hdr);
-            if ((rc = upload(c, m, plan.groups.data(), plan.groups.size(), &dg)) != HISPMV_OK) return rc;
-            if ((rc = upload(c, m, m.st.words.data(), m.st.words.size(), &dw)) != HISPMV_OK) return rc;
-            if ((rc = upload(c, m, m.st.hdr.data(), m.st.hdr.size(), &dh)) != HISPMV_OK) return rc;
-            if ((rc = upload(c, m, m.fix_short.data(), m.fix_short.size(), &fs)) != HISPMV_OK) return rc;
-            if ((rc = upload(c, m, m.fix_long.data(), m.fix_long.size(), &fl)) != HISPMV_OK) return rc;
-            void* carry = nullptr;
-            HIP_TRY(c, hipMalloc(&carry, (size_t)std::max<int64_t>(m.n_slices, 1) * sizeof(float)));
-            m.allocs.push_back(carry);
-            HIP_TRY(c, hipMemsetAsync(carry, 0, (size_t)std::max<int64_t>(m.n_slices, 1) * sizeof(float), c->stream));
-            m.dev.words = dw; m.dev.hdr = (const int4*)dh;
-            m.dev.fix_short = (const int4*)fs; m.dev.fix_long = (const int4*)fl;
-            m.dev.carry = (float*)carry;
-            {   // carry granules {value, launch tag} and the group ticket of the single-launch variant
-                void *gran = nullptr, *ticket = nullptr;
-                const size_t gb = (size_t)std::max<int64_t>(m.n_slices, 1) * sizeof(unsigned long long);
-                HIP_TRY(c, hipMalloc(&gran, gb));
+            for (auto& p : m.parts) {
+                const uint64_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
+                const int2* dg = nullptr;
+                const int64_t ns = p.st.n_slices;
+                if ((rc = upload(c, m, p.plan.groups.data(), p.plan.groups.size(), &dg)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.st.words.data(), p.st.words.size(), &dw)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.st.hdr.data(), p.st.hdr.size(), &dh)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.fix_short.data(), p.fix_short.size(), &fs)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.fix_long.data(), p.fix_long.size(), &fl)) != HISPMV_OK) return rc;
+                // carry per slice; {carry, launch tag} granules and the group ticket of the look-back variant
+                void *carry = nullptr, *gran = nullptr, *ticket = nullptr;
+                const size_t n1 = (size_t)std::max<int64_t>(ns, 1);
+                HIP_TRY(c, hipMalloc(&carry, n1 * sizeof(float)));
+                m.allocs.push_back(carry);
+                HIP_TRY(c, hipMemsetAsync(carry, 0, n1 * sizeof(float), c->stream));
+                HIP_TRY(c, hipMalloc(&gran, n1 * sizeof(unsigned long long)));
                 m.allocs.push_back(gran);
-                HIP_TRY(c, hipMemsetAsync(gran, 0, gb, c->stream));
+                HIP_TRY(c, hipMemsetAsync(gran, 0, n1 * sizeof(unsigned long long), c->stream));
                 HIP_TRY(c, hipMalloc(&ticket, sizeof(unsigned long long)));
                 m.allocs.push_back(ticket);
                 HIP_TRY(c, hipMemsetAsync(ticket, 0, sizeof(unsigned long long), c->stream));
-                m.dev.gran = (unsigned long long*)gran; m.dev.ticket = (unsigned long long*)ticket;
-                m.dev.err = c->d_err; m.dev.lookback = c->use_lookback; m.dev.launches = 0;
+                SpmvDeviceMatrix& d = p.dev;
+                d.words = dw; d.hdr = (const int4*)dh; d.groups = dg;
+                d.fix_short = (const int4*)fs; d.fix_long = (const int4*)fl;
+                d.carry = (float*)carry; d.gran = (unsigned long long*)gran; d.ticket = (unsigned long long*)ticket;
+                d.err = c->d_err; d.launches = 0; d.ticket_launches = 0;
+                d.n_slices = ns; d.n_groups = (ns + p.plan.group_slices - 1) / p.plan.group_slices;
+                d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads; d.lds_floats = p.plan.lds_floats;
+                d.n_fix_short = (int32_t)p.fix_short.size(); d.n_fix_long = (int32_t)p.fix_long.size();
+                d.rows = m.rows; d.cols = m.cols;
+                // co-residency of the whole grid: workgroups per CU by LDS and waves (conservative: <= 4 blocks,
+                // <= 16 waves per CU; MI355X_MICROARCH.md "Residency")
+                const int lds_b = std::max(1, d.lds_floats * 4 + 64);
+                const int per_cu = std::max(1, std::min({4, (160 * 1024) / lds_b, 16 / (d.block_threads / 64)}));
+                // ... and every slice must be (nearly) in flight at once: with long per-wave chunks the owner of a
+                // workgroup's first slice would wait for the predecessor's LAST slice, i.e. for its whole chunk.
+                const bool resident = d.n_groups <= (int64_t)c->n_cus * per_cu && d.group_slices <= 2 * (d.block_threads / 64);
+                d.lookback = c->carry_mode == 1 || (c->carry_mode == 2 && resident);
+                d.use_ticket = !resident;
             }
-            m.dev.groups = dg; m.dev.n_groups = (int64_t)((m.n_slices + plan.group_slices - 1) / plan.group_slices);
-            m.dev.group_slices = plan.group_slices; m.dev.block_threads = plan.block_threads; m.dev.lds_floats = plan.lds_floats;
-            m.plan_threads = plan.block_threads; m.plan_group = plan.group_slices; m.plan_lds = plan.lds_floats;
-            m.dev.n_slices = m.n_slices;
-            m.dev.n_fix_short = (int32_t)m.fix_short.size(); m.dev.n_fix_long = (int32_t)m.fix_long.size();
-            m.dev.rows = m.rows; m.dev.cols = m.cols;
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // host copies are no longer needed
-        m.st = SliceStream{}; m.fix_short = {}; m.fix_long = {}; m.dense_host = {};
+        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; }
+        m.dense_host = {};
         m.loaded = true;
     }
     return HISPMV_OK;
@@ -507,6 +621,8 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->n_slices = m.n_slices; out->n_elems = m.n_elems; out->n_split_rows = m.n_split;
     out->device_bytes = m.device_bytes; out->prep_seconds = m.prep_seconds;
     out->block_threads = m.plan_threads; out->group_slices = m.plan_group; out->lds_bytes = m.plan_lds * 4;
+    out->col_tiles = (int32_t)m.parts.size();
+    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->reserved = 0;
     return HISPMV_OK;
 }
 

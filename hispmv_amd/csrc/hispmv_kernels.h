@@ -23,6 +23,8 @@ struct SpmvDeviceMatrix {
     unsigned long long* ticket = nullptr;   // group tickets, monotonic over launches
     int* err = nullptr;                     // set to 1 if a bounded wait expired
     unsigned long long launches = 0;        // launches so far (host side)
+    unsigned long long ticket_launches = 0; // launches that drew tickets
+    bool use_ticket = true;                 // false when the whole grid is co-resident (no ordering needed)
     int64_t n_slices = 0;
     int32_t n_fix_short = 0, n_fix_long = 0;
     int32_t rows = 0, cols = 0;
@@ -34,6 +36,7 @@ struct LookbackArgs {
     int* err;
     unsigned long long ticket_base;
     unsigned epoch;
+    int use_ticket;
 };
 
 constexpr int kFixShortMax = 32;

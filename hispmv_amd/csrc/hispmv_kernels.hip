@@ -74,12 +74,20 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
 // No global store sits between a slice's loads, so hipcc keeps them all in flight together.
 // ---------------------------------------------------------------------------
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
-__global__ __launch_bounds__(1024) void spmv_slices_kernel(
+__global__ __launch_bounds__(512) void spmv_slices_kernel(
     const uint4* __restrict__ words, const int4* __restrict__ hdr, const int2* __restrict__ groups,
-    const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
+    const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int cols, LookbackArgs lb) {
+    int lds_floats, int cols, int rows, LookbackArgs lb) {
     extern __shared__ float xs[];
+    // x, bias and y are reached through buffer descriptors: 32-bit byte offsets instead of 64-bit
+    // addresses (half the address VGPRs, one shift per gather), and the hardware range check turns an
+    // offset of 0xffffffff into "no access" -- the predicate of the bias loads and y stores costs no branch,
+    // so hipcc counts every load exactly and the prefetch below really stays in flight.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, cols * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, rows * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, rows * 4, 0x00020000);
+    constexpr unsigned kNoAccess = 0xffffffffu;
     __shared__ long long s_group;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
@@ -89,10 +97,31 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         // may have to wait for belongs to a workgroup that is already running or done -- the carry
         // look-back below cannot deadlock whatever order the dispatcher picks.  The ticket counter is
         // never reset: launch k consumes tickets [k*n_groups, (k+1)*n_groups).
-        if (threadIdx.x == 0)
-            s_group = (long long)(__hip_atomic_fetch_add(lb.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - lb.ticket_base);
-        __syncthreads();
-        group = s_group;
+        // When the whole grid is co-resident (lb.use_ticket == 0, decided on the host from the launch
+        // plan) every workgroup is running anyway and blockIdx order needs no ticket.
+        if (lb.use_ticket) {
+            if (threadIdx.x == 0)
+                s_group = (long long)(__hip_atomic_fetch_add(lb.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - lb.ticket_base);
+            __syncthreads();
+            group = s_group;
+        }
+    }
+
+    const long long first = group * group_slices;
+    const long long last = (first + group_slices < n_slices) ? first + group_slices : n_slices;   // exclusive
+
+    // MM2S_A, software-pipelined: the slice a wavefront works on was requested one iteration earlier
+    // (8 x global_load_dwordx4 = the whole 8 KiB, plus its header), so the HBM latency of slice k+1 hides
+    // behind the gathers, scans and stores of slice k.  The first request goes out BEFORE the x window is
+    // staged: it depends on nothing but the slice id.
+    long long slice = first + wave;
+    uint4 w[kSliceSteps];
+    int4 h = int4{0, 0, 0, 0};
+    if (slice < last) {
+        const uint4* p = words + slice * (kSliceElems / 2) + lane;
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) w[j] = p[j * 64];
+        h = hdr[slice];
     }
 
     int x_base = 0;
@@ -110,49 +139,74 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         }
         __syncthreads();
     }
-    const long long first = group * group_slices;
 
-    for (long long slice = first + wave; slice < first + group_slices && slice < n_slices; slice += n_waves) {
-        // MM2S_A: the whole 8 KiB slice in flight at once, 16 B per lane per load
-        const uint4* p = words + slice * (kSliceElems / 2) + lane;
-        uint4 w[kSliceSteps];
-#pragma unroll
-        for (int j = 0; j < kSliceSteps; ++j) w[j] = p[j * 64];
-        const int4 h = hdr[slice];
+    while (slice < last) {
         int row = __builtin_amdgcn_readfirstlane(h.x);
         const int row_first = row;                                   // first row that ends in this slice
         const int chain_len = __builtin_amdgcn_readfirstlane(h.y);   // >0: that row began chain_len slices earlier
 
-        // ComputeAB: val * x[col]
-        float p0[kSliceSteps], p1[kSliceSteps];
+        // Row ids of every row end (ballot + mbcnt prefix counts; no per-element row field) -- computed
+        // first so that the bias loads can leave together with the x gathers.
+        int r0[kSliceSteps];
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64((w[j].y & kRowEndBit) != 0);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64((w[j].w & kRowEndBit) != 0);
+            r0[j] = row + lanes_below(m0) + lanes_below(m1);
+            row += __builtin_popcountll(m0) + __builtin_popcountll(m1);
+        }
+
+        // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather) and, for Compute_C, bias[row]
+        float x0[kSliceSteps], x1[kSliceSteps], b0[kSliceSteps], b1[kSliceSteps];
         if (USE_LDS && in_lds) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                p0[j] = i2f((int)w[j].x) * xs[(int)(w[j].y & ~kRowEndBit) - x_base];
-                p1[j] = i2f((int)w[j].z) * xs[(int)(w[j].w & ~kRowEndBit) - x_base];
+                x0[j] = xs[(int)(w[j].y & ~kRowEndBit) - x_base];
+                x1[j] = xs[(int)(w[j].w & ~kRowEndBit) - x_base];
             }
         } else {
-            float x0[kSliceSteps], x1[kSliceSteps];
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                x0[j] = x[w[j].y & ~kRowEndBit];
-                x1[j] = x[w[j].w & ~kRowEndBit];
+                x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w[j].y & ~kRowEndBit) << 2, 0, 0));
+                x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w[j].w & ~kRowEndBit) << 2, 0, 0));
             }
+        }
+        if (HAS_BETA) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                p0[j] = i2f((int)w[j].x) * x0[j];
-                p1[j] = i2f((int)w[j].z) * x1[j];
+                const bool e0 = (w[j].y & kRowEndBit) != 0, e1 = (w[j].w & kRowEndBit) != 0;
+                b0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, e0 ? (unsigned)r0[j] << 2 : kNoAccess, 0, 0));
+                b1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, e1 ? (unsigned)(r0[j] + (e0 ? 1 : 0)) << 2 : kNoAccess, 0, 0));
             }
+        }
+
+        // ComputeAB: val * x[col]; keep only the row-end flags of this slice, then request the next slice
+        // into the same registers (issued AFTER this slice's gathers so that waiting for the gathers does not
+        // wait for the prefetch: vmcnt retires in issue order).
+        float p0[kSliceSteps], p1[kSliceSteps];
+        unsigned ends = 0;     // bit 2j = e0 of step j, bit 2j+1 = e1
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            p0[j] = i2f((int)w[j].x) * x0[j];
+            p1[j] = i2f((int)w[j].z) * x1[j];
+            ends |= ((w[j].y >> 31) << (2 * j)) | ((w[j].w >> 31) << (2 * j + 1));
+        }
+        const long long cur = slice;
+        slice += n_waves;
+        if (slice < last) {
+            const uint4* p = words + slice * (kSliceElems / 2) + lane;
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) w[j] = p[j * 64];
+            h = hdr[slice];
         }
 
         // PreAccumulator + row distribution network: segmented scan per 128-element step
         float t0[kSliceSteps], t1[kSliceSteps];
-        int r0[kSliceSteps];
         float carry_step = 0.0f;       // partial sum of the row left open by the previous step
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            const bool e0 = (w[j].y & kRowEndBit) != 0;
-            const bool e1 = (w[j].w & kRowEndBit) != 0;
+            const bool e0 = (ends >> (2 * j)) & 1u;
+            const bool e1 = (ends >> (2 * j + 1)) & 1u;
             // what this lane hands to its right neighbour, and whether it cuts the chain
             float v = e1 ? 0.0f : (e0 ? p1[j] : p0[j] + p1[j]);
             int F = (e0 | e1) ? 1 : 0;
@@ -161,26 +215,22 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
             // incoming partial for this lane = inclusive value of the lane below (lane 0: previous step)
             const float cin = i2f(__builtin_amdgcn_update_dpp(f2i(carry_step), f2i(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
             carry_step = i2f(__builtin_amdgcn_readlane(f2i(v), 63));
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(e0);
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(e1);
-            r0[j] = row + lanes_below(m0) + lanes_below(m1);
             t0[j] = cin + p0[j];
             t1[j] = e0 ? p1[j] : cin + (p0[j] + p1[j]);
-            row += __builtin_popcountll(m0) + __builtin_popcountll(m1);
         }
 
         float chain = 0.0f;
         if (LOOKBACK) {
             // publish this slice's open partial sum as ONE 8-byte {value, launch tag} granule ...
             if (lane == 0)
-                __hip_atomic_store(lb.gran + slice, ((unsigned long long)lb.epoch << 32) | (unsigned)f2i(carry_step),
+                __hip_atomic_store(lb.gran + cur, ((unsigned long long)lb.epoch << 32) | (unsigned)f2i(carry_step),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // ... and collect the parts of the first row that earlier slices hold (rows "shared" between
             // wavefronts): lane k polls the granule of slice (s - chain_len + k); fixed summation order.
             if (chain_len > 0) {
                 float part = 0.0f;
                 for (int k = lane; k < chain_len; k += 64) {
-                    const unsigned long long* g = lb.gran + (slice - chain_len + k);
+                    const unsigned long long* g = lb.gran + (cur - chain_len + k);
                     unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     int spins = 0;
                     while ((unsigned)(v >> 32) != lb.epoch && spins < kLookbackSpinMax) {
@@ -192,41 +242,26 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
                     part += i2f((int)(unsigned)v);
                 }
                 chain = wave_sum(part);
+#pragma unroll
+                for (int j = 0; j < kSliceSteps; ++j) {
+                    const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
+                    if (e0 && r0[j] == row_first) t0[j] += chain;
+                    else if (!e0 && e1 && r0[j] == row_first) t1[j] += chain;
+                }
             }
         }
 
-        // Compute_C: beta*c_in + alpha*acc for the rows that end in this slice
-        if (LOOKBACK && chain_len > 0) {
+        // Compute_C: beta*c_in + alpha*acc for the rows that end in this slice (consecutive rows: the
+        // predicated dword stores of a step coalesce)
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (w[j].y & kRowEndBit) != 0;
-                if (e0 && r0[j] == row_first) t0[j] += chain;
-                else if (!e0 && (w[j].w & kRowEndBit) != 0 && r0[j] == row_first) t1[j] += chain;
-            }
+        for (int j = 0; j < kSliceSteps; ++j) {
+            const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
+            const float y0 = HAS_BETA ? alpha * t0[j] + beta * b0[j] : alpha * t0[j];
+            const float y1 = HAS_BETA ? alpha * t1[j] + beta * b1[j] : alpha * t1[j];
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(y0), ry, e0 ? (unsigned)r0[j] << 2 : kNoAccess, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(y1), ry, e1 ? (unsigned)(r0[j] + (e0 ? 1 : 0)) << 2 : kNoAccess, 0, 0);
         }
-        if (HAS_BETA) {
-            float b0[kSliceSteps], b1[kSliceSteps];
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (w[j].y & kRowEndBit) != 0, e1 = (w[j].w & kRowEndBit) != 0;
-                b0[j] = e0 ? bias[r0[j]] : 0.0f;
-                b1[j] = e1 ? bias[r0[j] + (e0 ? 1 : 0)] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (w[j].y & kRowEndBit) != 0, e1 = (w[j].w & kRowEndBit) != 0;
-                if (e0) y[r0[j]] = alpha * t0[j] + beta * b0[j];
-                if (e1) y[r0[j] + (e0 ? 1 : 0)] = alpha * t1[j] + beta * b1[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (w[j].y & kRowEndBit) != 0, e1 = (w[j].w & kRowEndBit) != 0;
-                if (e0) y[r0[j]] = alpha * t0[j];
-                if (e1) y[r0[j] + (e0 ? 1 : 0)] = alpha * t1[j];
-            }
-        }
-        if (!LOOKBACK && lane == 0) carry[slice] = carry_step;
+        if (!LOOKBACK && lane == 0) carry[cur] = carry_step;
     }
 }
 
@@ -262,7 +297,7 @@ static void launch_slices(const SpmvDeviceMatrix& m, const LookbackArgs& lb, con
     const size_t lds = USE_LDS ? (size_t)m.lds_floats * sizeof(float) : 0;
     hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS, LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
                        (const uint4*)m.words, m.hdr, m.groups, x, bias, y, m.carry, alpha, beta,
-                       (long long)m.n_slices, m.group_slices, m.lds_floats, m.cols, lb);
+                       (long long)m.n_slices, m.group_slices, m.lds_floats, m.cols, m.rows, lb);
 }
 
 template <bool HAS_BETA, bool USE_LDS>
@@ -290,7 +325,9 @@ hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, f
         LookbackArgs lb{};
         if (m.lookback) {
             lb.gran = m.gran; lb.ticket = m.ticket; lb.err = m.err;
-            lb.ticket_base = m.launches * (unsigned long long)m.n_groups;
+            lb.use_ticket = m.use_ticket ? 1 : 0;
+            lb.ticket_base = m.ticket_launches * (unsigned long long)m.n_groups;
+            if (m.use_ticket) m.ticket_launches++;
             lb.epoch = (unsigned)(m.launches % 0xffffffffull) + 1u;   // never 0: tag 0 means "never written"
             m.launches++;
         }

@@ -104,6 +104,8 @@ Coo read_mtx(const std::string& path, MtxFlavor flavor) {
 // ---------------------------------------------------------------------------
 Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const int32_t* c, const float* v) {
     if (rows < 0 || cols < 0 || nnz < 0) throw std::out_of_range("negative dimension");
+    // the kernels address x, bias and y with 32-bit byte offsets (buffer descriptors)
+    if (rows >= (1 << 30) || cols >= (1 << 30)) throw std::out_of_range("dimension >= 2^30 is not supported");
     Csr m;
     m.rows = rows; m.cols = cols;
     m.row_ptr.assign((size_t)rows + 1, 0);

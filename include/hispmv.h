@@ -122,6 +122,8 @@ typedef struct hispmv_matrix_info {
     int32_t block_threads;  /* launch plan chosen at load time: workgroup size, */
     int32_t group_slices;   /*   slices per workgroup, */
     int32_t lds_bytes;      /*   LDS bytes of the x window (0 = x gathered through L2) */
+    int32_t col_tiles;      /* number of column tiles (1 = untiled) */
+    int32_t carry_lookback; /* 1 = rows shared between slices are merged inside the launch (look-back), 0 = fix-up launch */
     int32_t reserved;
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);

@@ -61,13 +61,13 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
     assert pl < 1e-5
     # the CPU model of the wavefront performs the same fp32 operations in the same order
     P = prep_from_mtx(GOLDEN / f"{name}.mtx", 1)
-    ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, rows, 0)   # default product path: fix-up variant
+    ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, rows, fpga.matrix_info(idx)["carry_lookback"])
     assert np.array_equal(y.view(np.uint32), ye.view(np.uint32)), "GPU result differs bitwise from the wavefront model"
     info = fpga.matrix_info(idx)
     assert info["nnz"] == g["ref_col_idx"].size and info["loaded"] == 1 and not info["is_dense"]
 
 
-@pytest.mark.parametrize("carry,mode", [("lookback", 1), ("fixup", 0)])
+@pytest.mark.parametrize("carry,mode", [("lookback", 1), ("fixup", 0), ("auto", None)])
 def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypatch, carry, mode):
     """Rows shared between slices: the two-launch fix-up variant (default) and the single-launch
     look-back (HISPMV_CARRY=lookback) each reproduce their CPU model bit for bit, on a matrix with
@@ -88,6 +88,10 @@ def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypat
     h.load_matrices()
     h.select_matrix(idx)
     P = prep_from_coo(r, c, v, rows, cols)
+    if mode is None:
+        mode = h.matrix_info(idx)["carry_lookback"]
+    else:
+        assert h.matrix_info(idx)["carry_lookback"] == mode
     y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, ALPHA, BETA)
     for _ in range(3):                      # repeated launches reuse the granules with a new launch tag
         y = np.full(rows, np.nan, np.float32)
@@ -96,6 +100,37 @@ def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypat
         ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, ALPHA, BETA, rows, mode)
         assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
     h.close()
+
+
+def test_column_tiled_scattered_matrix(fpga):
+    """x larger than 1.5x the column-tile budget (4 MiB) with scattered columns: the matrix is cut into column
+    tiles (the reference's column tiling, spmv-helper.cpp:242-263); tile 0 applies beta*bias, later tiles
+    accumulate in place.  Bit-exact against the wavefront model applied tile by tile."""
+    from hispmv_amd.prep import prep_from_coo
+    rng = np.random.default_rng(13)
+    rows, cols, nnz = 150000, 1800000, 1500000
+    r = rng.integers(0, rows, nnz).astype(np.int32)
+    c = rng.integers(0, cols, nnz).astype(np.int32)
+    v = rng.random(nnz, dtype=np.float32) - 0.5
+    x = rng.random(cols, dtype=np.float32)
+    b = rng.random(rows, dtype=np.float32)
+    idx = fpga.create_sparse_handle(r, c, v, rows, cols)
+    fpga.load_matrices()
+    info = fpga.matrix_info(idx)
+    tiles = -(-cols * 4 // (4 << 20))
+    width = (-(-cols // tiles) + 63) & ~63
+    assert info["col_tiles"] == -(-cols // width) == 2 and info["lds_bytes"] == 0
+    y = np.zeros(rows, np.float32)
+    fpga.select_matrix(idx)
+    fpga.run_kernel(x, b, y, ALPHA, BETA)
+    y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
+    assert bwd_err(y, y64, mag) < TOL
+    ye = None
+    for t in range(info["col_tiles"]):
+        sel = (c >= t * width) & (c < (t + 1) * width)
+        P = prep_from_coo(r[sel], c[sel], v[sel], rows, cols)
+        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b if t == 0 else ye, ALPHA, BETA if t == 0 else 1.0, rows, info["carry_lookback"])
+    assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
 
 
 def test_general_test_call_sequence_scaled(fpga):
