@@ -47,24 +47,26 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-matrix-reps", type=int, default=10)
     ap.add_argument("--details", type=str, default="", help="write the per-matrix table to this JSON file")
+    ap.add_argument("--standin", choices=["structured", "uniform"], default="structured",
+                    help="stand-in family of the mesh-origin matrices: structured FEM-like (default) or unstructured band")
     return ap.parse_args()
 
 
-def load_set(names, rank, world):
+def load_set(names, rank, world, uniform=False):
     """-> list of dicts with the rank's CSR shard of every matrix (host arrays)."""
     from hispmv_amd import matrices as M
     out = []
-    for name, rows, nnz, fam, bw in M.SUITESPARSE_SET:
+    import zlib
+    for name, rows, nnz, fam, par in M.SUITESPARSE_SET:
         if names and name not in names:
             continue
         real = M.real_matrix_path(name)
         if real is not None and world == 1:
             out.append(dict(name=name, source="file:" + str(real), path=str(real)))
             continue
-        import zlib
         seed = zlib.crc32(name.encode()) + rank       # rank k's block of the N-fold scaled matrix
-        rp, ci, va = M.synth_csr(rows, rows, nnz, fam, bw, seed)
-        out.append(dict(name=name, source=f"synthetic:{fam}", rows=rows, cols=rows, nnz=nnz, rp=rp, ci=ci, va=va))
+        rp, ci, va, used = M.make_standin(name, rows, nnz, fam, par, seed, uniform)
+        out.append(dict(name=name, source=f"synthetic:{used}", rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
     return out
 
 
@@ -134,7 +136,7 @@ def main():
 
     names = [n for n in args.matrices.split(",") if n]
     t0 = time.time()
-    mats = load_set(names, rank, world)
+    mats = load_set(names, rank, world, args.standin == "uniform")
     t_gen = time.time() - t0
 
     fpga = pyhispmv.FpgaHandle(HW[0], local_rank, *HW[1:])

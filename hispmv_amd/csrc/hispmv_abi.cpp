@@ -144,9 +144,10 @@ GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus) {
     // resident workgroups per CU at that cap
     struct Cfg { int threads, slices, cap, per_cu; };
     const Cfg cfgs[] = {
-        {256, 8, 10 * 1024, 4},            // small windows: many small workgroups
-        {512, 16, 20 * 1024, 2},
-        {512, 0, 20 * 1024 - 256, 2},      // persistent: 2 workgroups per CU, window staged once per workgroup
+        // (caps leave room for the row-total tiles: up to 1024 floats per wavefront)
+        {256, 8, 6 * 1024, 4},             // small windows: many small workgroups
+        {512, 16, 12 * 1024, 2},
+        {512, 0, 12 * 1024, 2},            // persistent: 2 workgroups per CU, window staged once per workgroup
         {512, 32, kMaxLdsFloats, 1},
         {512, 0, kMaxLdsFloats, 1},        // persistent: 1 workgroup per CU
     };
@@ -480,7 +481,16 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 const int64_t ns = p.st.n_slices;
                 if ((rc = upload(c, m, p.plan.groups.data(), p.plan.groups.size(), &dg)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.st.words.data(), p.st.words.size(), &dw)) != HISPMV_OK) return rc;
-                if ((rc = upload(c, m, p.st.hdr.data(), p.st.hdr.size(), &dh)) != HISPMV_OK) return rc;
+                // device header: {row_base, chain_len, rows ending in the slice, 0} (the column window of a slice is
+                // only needed by the planner)
+                std::vector<SliceHdr>& hh = p.st.hdr;
+                int max_rows = 1;
+                for (int64_t sl = 0; sl < ns; ++sl) {
+                    const int nr = (sl + 1 < ns ? hh[sl + 1].row_base : m.rows) - hh[sl].row_base;
+                    hh[sl].x_base = nr; hh[sl].x_span = 0;
+                    max_rows = std::max(max_rows, nr);
+                }
+                if ((rc = upload(c, m, hh.data(), hh.size(), &dh)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.fix_short.data(), p.fix_short.size(), &fs)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.fix_long.data(), p.fix_long.size(), &fl)) != HISPMV_OK) return rc;
                 // carry per slice; {carry, launch tag} granules and the group ticket of the look-back variant
@@ -502,11 +512,12 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.err = c->d_err; d.launches = 0; d.ticket_launches = 0;
                 d.n_slices = ns; d.n_groups = (ns + p.plan.group_slices - 1) / p.plan.group_slices;
                 d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads; d.lds_floats = p.plan.lds_floats;
+                d.ytile_floats = std::min(kSliceElems, (max_rows + 63) & ~63);
                 d.n_fix_short = (int32_t)p.fix_short.size(); d.n_fix_long = (int32_t)p.fix_long.size();
                 d.rows = m.rows; d.cols = m.cols;
                 // co-residency of the whole grid: workgroups per CU by LDS and waves (conservative: <= 4 blocks,
                 // <= 16 waves per CU; MI355X_MICROARCH.md "Residency")
-                const int lds_b = std::max(1, d.lds_floats * 4 + 64);
+                const int lds_b = std::max(1, (d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 + 64);
                 const int per_cu = std::max(1, std::min({4, (160 * 1024) / lds_b, 16 / (d.block_threads / 64)}));
                 // ... and every slice must be (nearly) in flight at once: with long per-wave chunks the owner of a
                 // workgroup's first slice would wait for the predecessor's LAST slice, i.e. for its whole chunk.

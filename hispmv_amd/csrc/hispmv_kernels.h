@@ -17,6 +17,7 @@ struct SpmvDeviceMatrix {
     int32_t group_slices = 8;           // slices per workgroup
     int32_t block_threads = 256;        // workgroup size (64 * wavefronts)
     int32_t lds_floats = 0;             // dynamic LDS (floats) for the x window; 0 = gather x from L2
+    int32_t ytile_floats = 1024;        // LDS floats per wavefront for the row totals of one slice (>= max rows ending in a slice)
     // single-launch carry hand-off between slices (look-back); when false the fix-up kernels run instead
     bool lookback = true;
     unsigned long long* gran = nullptr;     // n_slices x {fp32 carry, launch tag}
@@ -40,7 +41,7 @@ struct LookbackArgs {
 };
 
 constexpr int kFixShortMax = 32;
-constexpr int kMaxLdsFloats = 40 * 1024 - 256;   // 160 KiB LDS per CU minus a little slack
+constexpr int kMaxLdsFloats = 30 * 1024;          // largest x window (120 KiB): leaves room for the row-total tiles
 
 // Once per process/device before the first launch (raises the dynamic-LDS limit of the slice kernels).
 hipError_t prepare_spmv_kernels();

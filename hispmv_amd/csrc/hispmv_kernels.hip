@@ -78,7 +78,8 @@ __global__ __launch_bounds__(512) void spmv_slices_kernel(
     const uint4* __restrict__ words, const int4* __restrict__ hdr, const int2* __restrict__ groups,
     const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int cols, int rows, LookbackArgs lb) {
+    int lds_floats, int ytile_floats, int cols, int rows, LookbackArgs lb) {
+    // LDS: [x window: lds_floats][row totals of the slice in flight: ytile_floats per wavefront]
     extern __shared__ float xs[];
     // x, bias and y are reached through buffer descriptors: 32-bit byte offsets instead of 64-bit
     // addresses (half the address VGPRs, one shift per gather), and the hardware range check turns an
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(512) void spmv_slices_kernel(
     __shared__ long long s_group;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    float* const ytile = xs + (USE_LDS ? lds_floats : 0) + wave * ytile_floats;
     long long group = blockIdx.x;
     if (LOOKBACK) {
         // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
@@ -145,8 +147,15 @@ __global__ __launch_bounds__(512) void spmv_slices_kernel(
         const int row_first = row;                                   // first row that ends in this slice
         const int chain_len = __builtin_amdgcn_readfirstlane(h.y);   // >0: that row began chain_len slices earlier
 
-        // Row ids of every row end (ballot + mbcnt prefix counts; no per-element row field) -- computed
-        // first so that the bias loads can leave together with the x gathers.
+        const int n_rows = __builtin_amdgcn_readfirstlane(h.z);      // rows that end in this slice
+        // Compute_C operand: the slice's rows are consecutive, so bias is read with coalesced loads that leave
+        // together with the x gathers (first 128 rows here, the rest in the epilogue loop).
+        float bpre0 = 0.0f, bpre1 = 0.0f;
+        if (HAS_BETA) {
+            bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (unsigned)(row_first + lane) << 2 : kNoAccess, 0, 0));
+            bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (unsigned)(row_first + lane + 64) << 2 : kNoAccess, 0, 0));
+        }
+        // Local row ids of every row end (ballot + mbcnt prefix counts; no per-element row field).
         int r0[kSliceSteps];
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(512) void spmv_slices_kernel(
         }
 
         // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather) and, for Compute_C, bias[row]
-        float x0[kSliceSteps], x1[kSliceSteps], b0[kSliceSteps], b1[kSliceSteps];
+        float x0[kSliceSteps], x1[kSliceSteps];
         if (USE_LDS && in_lds) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
@@ -171,15 +180,6 @@ __global__ __launch_bounds__(512) void spmv_slices_kernel(
                 x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w[j].w & ~kRowEndBit) << 2, 0, 0));
             }
         }
-        if (HAS_BETA) {
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (w[j].y & kRowEndBit) != 0, e1 = (w[j].w & kRowEndBit) != 0;
-                b0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, e0 ? (unsigned)r0[j] << 2 : kNoAccess, 0, 0));
-                b1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, e1 ? (unsigned)(r0[j] + (e0 ? 1 : 0)) << 2 : kNoAccess, 0, 0));
-            }
-        }
-
         // ComputeAB: val * x[col]; keep only the row-end flags of this slice, then request the next slice
         // into the same registers (issued AFTER this slice's gathers so that waiting for the gathers does not
         // wait for the prefetch: vmcnt retires in issue order).
@@ -251,15 +251,24 @@ __global__ __launch_bounds__(512) void spmv_slices_kernel(
             }
         }
 
-        // Compute_C: beta*c_in + alpha*acc for the rows that end in this slice (consecutive rows: the
-        // predicated dword stores of a step coalesce)
+        // AccumBuffer -> Compute_C: the row totals go through this wavefront's LDS tile (one ds_write per row
+        // end) and leave as COALESCED y = alpha*total + beta*bias stores: ceil(n_rows/64) load/store pairs per
+        // slice instead of 32 mostly-empty predicated ones (the output phase cost 25-30 % that way).
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
-            const float y0 = HAS_BETA ? alpha * t0[j] + beta * b0[j] : alpha * t0[j];
-            const float y1 = HAS_BETA ? alpha * t1[j] + beta * b1[j] : alpha * t1[j];
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(y0), ry, e0 ? (unsigned)r0[j] << 2 : kNoAccess, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(y1), ry, e1 ? (unsigned)(r0[j] + (e0 ? 1 : 0)) << 2 : kNoAccess, 0, 0);
+            if (e0) ytile[r0[j] - row_first] = t0[j];
+            if (e1) ytile[r0[j] - row_first + (e0 ? 1 : 0)] = t1[j];
+        }
+        for (int i = lane; i < n_rows; i += 64) {
+            const float t = ytile[i];
+            if (HAS_BETA) {
+                const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
+                              : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(row_first + i) << 2, 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (unsigned)(row_first + i) << 2, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, (unsigned)(row_first + i) << 2, 0, 0);
+            }
         }
         if (!LOOKBACK && lane == 0) carry[cur] = carry_step;
     }
@@ -294,10 +303,10 @@ __global__ __launch_bounds__(256) void spmv_fixup_long_kernel(const int4* __rest
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
 static void launch_slices(const SpmvDeviceMatrix& m, const LookbackArgs& lb, const float* x, const float* bias, float* y,
                           float alpha, float beta, hipStream_t stream) {
-    const size_t lds = USE_LDS ? (size_t)m.lds_floats * sizeof(float) : 0;
+    const size_t lds = ((USE_LDS ? (size_t)m.lds_floats : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float);
     hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS, LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
                        (const uint4*)m.words, m.hdr, m.groups, x, bias, y, m.carry, alpha, beta,
-                       (long long)m.n_slices, m.group_slices, m.lds_floats, m.cols, m.rows, lb);
+                       (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, lb);
 }
 
 template <bool HAS_BETA, bool USE_LDS>
@@ -310,11 +319,15 @@ static void launch_slices2(const SpmvDeviceMatrix& m, const LookbackArgs& lb, co
 hipError_t prepare_spmv_kernels() {
     // the x window may use (almost) the whole 160 KiB LDS of a CU
     hipError_t e;
-    const int max_lds = kMaxLdsFloats * (int)sizeof(float);
+    const int max_lds = 160 * 1024 - 256;   // the kernels also hold a few bytes of static LDS
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     return hipSuccess;
 }
 

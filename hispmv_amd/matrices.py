@@ -4,8 +4,12 @@
 
 Every stand-in keeps the real matrix's rows and (post-loader) nnz from BASELINE.md section 2 and is
 drawn from one of two families:
-  banded    FEM-like: row lengths ~ Poisson(nnz/rows), columns spread (jittered strata) over +-w of
-            the diagonal, no forced runs of consecutive columns (pessimistic for x locality)
+  fem       structured-mesh / FEM-like (matrices that come from meshes): `dofs` unknowns per node, each node
+            coupled to a fixed stencil of neighbour offsets (clusters of consecutive nodes inside a band),
+            dense dofs x dofs blocks, couplings dropped at random to hit the exact nnz
+  banded    row lengths ~ Poisson(nnz/rows), columns spread (jittered strata) over +-w of the diagonal, no
+            column reuse between rows (circuit / optimisation matrices; also the pessimistic variant of the
+            FEM ones: bench.py --standin uniform)
   scattered columns spread over the whole width; `powerlaw` adds bounded power-law row lengths
 Real .mtx files, if the user drops them under matrices/<name>/<name>.mtx, are used instead.
 """
@@ -16,24 +20,30 @@ from pathlib import Path
 
 import numpy as np
 
-# name, rows(=cols), nnz after the reference loader, family, half-bandwidth (banded only)
+# Half-bandwidths used when the FEM-origin matrices are generated with the unstructured `banded` family
+# instead (bench.py --standin uniform): the pessimistic variant, no column reuse between rows.
+UNIFORM_BAND = {"PFlow_742": 20000, "TSOPF_RS_b2383": 2400, "Si41Ge41H72": 30000, "crankseg_2": 6000, "nd6k": 3000,
+                "thread": 3000, "crystk03": 1500, "ford2": 5000}
+
+# name, rows(=cols), nnz after the reference loader, family, parameter:
+#   fem -> (dofs per node, run of consecutive neighbour nodes, half band in nodes); banded -> half bandwidth
 SUITESPARSE_SET = [
-    ("PFlow_742", 742793, 37138400, "banded", 20000),
+    ("PFlow_742", 742793, 37138400, "fem", (1, 4, 30000)),
     ("soc-Pokec", 1632803, 30622600, "powerlaw", 0),
     ("mouse_gene", 45101, 28967300, "scattered", 0),
-    ("TSOPF_RS_b2383", 38120, 16171200, "banded", 2400),
-    ("Si41Ge41H72", 185639, 15011300, "banded", 30000),
-    ("crankseg_2", 63838, 14148850, "banded", 6000),
-    ("nd6k", 18000, 6897300, "banded", 3000),
-    ("thread", 29736, 4444880, "banded", 3000),
+    ("TSOPF_RS_b2383", 38120, 16171200, "fem", (8, 2, 300)),
+    ("Si41Ge41H72", 185639, 15011300, "fem", (1, 8, 40000)),
+    ("crankseg_2", 63838, 14148850, "fem", (3, 2, 8000)),
+    ("nd6k", 18000, 6897300, "fem", (3, 2, 2500)),
+    ("thread", 29736, 4444880, "fem", (3, 2, 3000)),
     ("ASIC_680k", 682862, 2639000, "scattered", 0),
     ("nxp1", 414604, 2655880, "banded", 50000),
     ("analytics", 303813, 2006130, "scattered", 0),
     ("boyd2", 466316, 1500400, "banded", 30000),
     ("language", 399130, 1189850, "powerlaw", 0),
-    ("crystk03", 24696, 1751180, "banded", 1500),
+    ("crystk03", 24696, 1751180, "fem", (3, 3, 1500)),
     ("trans5", 116835, 749800, "banded", 20000),
-    ("ford2", 100196, 544690, "banded", 5000),
+    ("ford2", 100196, 544690, "fem", (1, 2, 8000)),
     ("lowThrust_7", 17378, 211560, "banded", 1000),
     ("c-52", 23948, 202710, "banded", 3000),
     ("hangGlider_3", 10260, 92700, "banded", 500),
@@ -102,17 +112,79 @@ def synth_csr(rows: int, cols: int, nnz: int, family: str, bandwidth: int = 0, s
     return row_ptr.astype(np.int32), col, val
 
 
+def synth_fem(rows: int, nnz: int, dofs: int, run: int, half_band_nodes: int, seed: int = 0):
+    """FEM / structured-mesh-like square matrix: `dofs` unknowns per node; node i couples to the nodes
+    i + o_k for a fixed set of offsets o_k (clusters of `run` consecutive nodes inside +-half_band_nodes,
+    like the planes/lines/points of a mesh stencil), each coupling kept with probability p so that the mean
+    row length is nnz/rows; a coupling is a dense dofs x dofs block (runs of `dofs` consecutive columns; the
+    `dofs` rows of a node share their column set; consecutive nodes have the same pattern shifted by one).
+    Exactly `nnz` entries (random surplus entries are dropped).  Columns ascending per row."""
+    rng = np.random.default_rng(seed)
+    d = int(dofs)
+    n_nodes = -(-rows // d)
+    L = nnz / rows
+    inside = max(0.3, 1.0 - half_band_nodes / (2.0 * n_nodes))       # share of (node, offset) pairs inside the matrix
+    K = max(1, int(np.ceil(1.2 * L / d / inside)))
+    n_clusters = max(1, -(-K // run))
+    starts = np.sort(rng.choice(np.arange(-half_band_nodes, half_band_nodes - run + 1), size=n_clusters, replace=False)) \
+        if 2 * half_band_nodes - run + 1 >= n_clusters else np.arange(n_clusters) * run - (n_clusters * run) // 2
+    off = np.unique(np.concatenate([starts + j for j in range(run)] + [np.zeros(1, dtype=np.int64)]))
+    K = off.size
+    p = min(1.0, 1.03 * L / (d * K * inside))
+    for _ in range(6):
+        keep = rng.random((n_nodes, K)) < p
+        nz_i, nz_k = np.nonzero(keep)
+        nb = nz_i + off[nz_k]
+        ok = (nb >= 0) & (nb < n_nodes)
+        nz_i, nb = nz_i[ok], nb[ok]
+        if nz_i.size * d * d >= nnz * 1.005 or p >= 1.0:
+            break
+        p = min(1.0, p * 1.05 * nnz / max(1, nz_i.size * d * d))
+    blocks = np.bincount(nz_i, minlength=n_nodes).astype(np.int64)          # couplings per node
+    seg_start = np.concatenate([[0], np.cumsum(blocks * d)])                # per node, in the expanded column list
+    E = (nb[:, None] * d + np.arange(d)[None, :]).reshape(-1)               # node's column list, ascending
+    row_len = np.repeat(blocks * d, d)[:rows]
+    rp = np.concatenate([[0], np.cumsum(row_len)])
+    total = int(rp[-1])
+    out_row = np.repeat(np.arange(rows, dtype=np.int64), row_len)
+    col = E[seg_start[out_row // d] + (np.arange(total, dtype=np.int64) - rp[out_row])]
+    alive = col < rows
+    surplus = int(alive.sum()) - nnz
+    if surplus > 0:
+        u = rng.random(total)
+        u[~alive] = 2.0
+        thr = np.partition(u, surplus)[surplus]
+        alive &= ~(u < thr)
+    col = col[alive].astype(np.int32)
+    out_row = out_row[alive]
+    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(out_row, minlength=rows))]).astype(np.int64)
+    n = int(row_ptr[-1])
+    val = rng.random(n, dtype=np.float32) * np.float32(2.0) - np.float32(1.0)
+    val[val == 0] = np.float32(0.5)
+    return row_ptr.astype(np.int32), col, val
+
+
 def synth_banded(rows, cols, nnz, bandwidth, seed=0):
     return synth_csr(rows, cols, nnz, "banded", bandwidth, seed)
 
 
-def suitesparse_standin(name: str):
+def make_standin(name: str, rows: int, nnz: int, fam: str, par, seed: int, uniform: bool = False):
+    """One stand-in -> (row_ptr, col_idx, values, family actually used)."""
+    if fam == "fem" and not uniform:
+        rp, ci, va = synth_fem(rows, nnz, par[0], par[1], par[2], seed)
+        return rp, ci, va, "fem"
+    if fam == "fem":
+        fam, par = "banded", UNIFORM_BAND[name]
+    rp, ci, va = synth_csr(rows, rows, nnz, fam, par if fam == "banded" else 0, seed)
+    return rp, ci, va, fam
+
+
+def suitesparse_standin(name: str, uniform: bool = False):
     """-> (rows, cols, row_ptr, col_idx, values, source) for one matrix of SUITESPARSE_SET."""
-    for n, rows, nnz, fam, bw in SUITESPARSE_SET:
+    for n, rows, nnz, fam, par in SUITESPARSE_SET:
         if n == name:
-            seed = zlib.crc32(name.encode())
-            rp, ci, va = synth_csr(rows, rows, nnz, fam, bw, seed)
-            return rows, rows, rp, ci, va, f"synthetic:{fam}"
+            rp, ci, va, used = make_standin(name, rows, nnz, fam, par, zlib.crc32(name.encode()), uniform)
+            return rows, rows, rp, ci, va, f"synthetic:{used}"
     raise KeyError(name)
 
 
