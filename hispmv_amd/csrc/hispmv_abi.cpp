@@ -52,7 +52,7 @@ struct Matrix {
     std::vector<Part> parts;
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0;
-    int plan_threads = 0, plan_group = 0, plan_lds = 0;
+    int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0;
     float* d_dense = nullptr;
     std::vector<void*> allocs;
 };
@@ -138,8 +138,17 @@ static int2 window_of(const std::vector<SliceHdr>& hdr, int64_t s0, int64_t s1) 
     return int2{lo, hi - lo};
 }
 
-GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus) {
+// LDS floats one wavefront needs for the row totals of a slice: the largest number of rows ending in one slice.
+static int ytile_floats_for(const std::vector<SliceHdr>& hdr, int32_t rows) {
+    int max_rows = 1;
+    for (size_t sl = 0; sl < hdr.size(); ++sl)
+        max_rows = std::max(max_rows, (sl + 1 < hdr.size() ? hdr[sl + 1].row_base : rows) - hdr[sl].row_base);
+    return std::min(kSliceElems, (max_rows + 63) & ~63);
+}
+
+GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus, int32_t rows) {
     const int64_t n = (int64_t)hdr.size();
+    const int ytile = ytile_floats_for(hdr, rows);
     // threads per workgroup, slices per workgroup (0 = one chunk per resident workgroup), LDS cap (floats),
     // resident workgroups per CU at that cap
     struct Cfg { int threads, slices, cap, per_cu; };
@@ -148,17 +157,27 @@ GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus) {
         {256, 8, 6 * 1024, 4},             // small windows: many small workgroups
         {512, 16, 12 * 1024, 2},
         {512, 0, 12 * 1024, 2},            // persistent: 2 workgroups per CU, window staged once per workgroup
-        {512, 32, kMaxLdsFloats, 1},
-        {512, 0, kMaxLdsFloats, 1},        // persistent: 1 workgroup per CU
+        {1024, 64, kMaxLdsFloats, 1},
+        {1024, 0, kMaxLdsFloats, 1},       // persistent: 1 workgroup (16 wavefronts) per CU
     };
     GroupPlan best;
     double best_cost = 1e300;
     bool have = false;
-    for (const Cfg& c : cfgs) {
+    const char* force = std::getenv("HISPMV_PLAN");          // experiments: "global" or an index into cfgs
+    const int only = (force && *force >= '0' && *force <= '9') ? std::atoi(force) : -1;
+    int cfg_index = -1;
+    for (const Cfg& c0 : cfgs) {
+        ++cfg_index;
+        if (force && (only < 0 || only != cfg_index)) continue;
+        Cfg c = c0;
+        // what is left of the CU's 160 KiB after the row-total tiles of the resident workgroups
+        c.cap = std::min(c.cap, ((160 * 1024 - 1024) / c.per_cu - ytile * (c.threads / 64) * 4) / 4);
+        if (c.cap < 256) continue;
         int64_t G = c.slices;
+        if (c.threads == 1024 && G != 0 && n / G < 512) continue;   // big workgroups only when there are plenty
         if (G == 0) {
             G = (n + (int64_t)n_cus * c.per_cu - 1) / ((int64_t)n_cus * c.per_cu);
-            if (G < 8) continue;                            // too little work to be worth a resident grid
+            if (G < 24) continue;                           // too little work to be worth a resident grid
         } else {
             if (n / G < 1024 && G > 4) G /= 2;              // small matrices: more, smaller workgroups
             if (n / G < 512 && G > 4) G /= 2;
@@ -173,9 +192,10 @@ GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus) {
         }
         const double frac = ng ? (double)ok / (double)ng : 0.0;
         if (frac < 0.9) continue;
-        // cost = x floats staged into LDS per stream element (lower is better); slight preference for more
-        // resident wavefronts
-        const double cost = (double)staged / (double)(n * kSliceElems) + 0.02 / (double)(c.per_cu * c.threads / 64);
+        // cost: x bytes staged into LDS relative to the stream bytes (L2 -> LDS is ~5x cheaper per byte than the
+        // HBM stream), plus a penalty for fewer than 16 resident wavefronts per CU
+        const int waves = c.per_cu * c.threads / 64;
+        const double cost = 0.2 * (double)staged * 4.0 / ((double)n * kSliceElems * 8.0) + 0.3 * std::max(0, 16 - waves) / 16.0;
         if (cost < best_cost) {
             best_cost = cost; have = true;
             best.block_threads = c.threads; best.group_slices = (int)G;
@@ -248,7 +268,7 @@ int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
 
 void finish_part(Matrix::Part& p, int n_cus) {
     for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
-    p.plan = plan_groups(p.st.hdr, n_cus);
+    p.plan = plan_groups(p.st.hdr, n_cus, p.st.rows);
 }
 
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
@@ -265,10 +285,12 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
     //  * x larger than an XCD's L2: L2-sized tiles.
     int32_t tw = 0;
     if (m->parts[0].plan.lds_floats == 0) {
-        if (csr.cols <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0) tw = ((csr.cols + 1) / 2 + 63) & ~63;
+        if (csr.cols <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096)
+            tw = ((csr.cols + 1) / 2 + 63) & ~63;
         else tw = column_tile_width(csr.cols, c->col_tile_bytes);
     }
     if (tw > 0) {
+        m->col_tile_width = tw;
         m->parts.clear();
         for (int32_t c0 = 0; c0 < csr.cols; c0 += tw) {
             m->parts.emplace_back();
@@ -513,15 +535,18 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.n_slices = ns; d.n_groups = (ns + p.plan.group_slices - 1) / p.plan.group_slices;
                 d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads; d.lds_floats = p.plan.lds_floats;
                 d.ytile_floats = std::min(kSliceElems, (max_rows + 63) & ~63);
+                if ((size_t)(d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 > 160 * 1024 - 512)
+                    return fail(c, HISPMV_EINVAL, "internal: launch plan exceeds the LDS of a CU");
                 d.n_fix_short = (int32_t)p.fix_short.size(); d.n_fix_long = (int32_t)p.fix_long.size();
                 d.rows = m.rows; d.cols = m.cols;
                 // co-residency of the whole grid: workgroups per CU by LDS and waves (conservative: <= 4 blocks,
                 // <= 16 waves per CU; MI355X_MICROARCH.md "Residency")
                 const int lds_b = std::max(1, (d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 + 64);
                 const int per_cu = std::max(1, std::min({4, (160 * 1024) / lds_b, 16 / (d.block_threads / 64)}));
-                // ... and every slice must be (nearly) in flight at once: with long per-wave chunks the owner of a
-                // workgroup's first slice would wait for the predecessor's LAST slice, i.e. for its whole chunk.
-                const bool resident = d.n_groups <= (int64_t)c->n_cus * per_cu && d.group_slices <= 2 * (d.block_threads / 64);
+                // ... and every slice must be in flight at once (one slice per wavefront): if a wavefront had a second
+                // slice, a workgroup's first slice would wait for the predecessor's LAST slice, which waits for that
+                // workgroup's first slice, ... -- one serial chain through the whole grid (measured: 14x slower).
+                const bool resident = d.n_groups <= (int64_t)c->n_cus * per_cu && d.group_slices <= d.block_threads / 64;
                 d.lookback = c->carry_mode == 1 || (c->carry_mode == 2 && resident);
                 d.use_ticket = !resident;
             }
@@ -633,7 +658,7 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->device_bytes = m.device_bytes; out->prep_seconds = m.prep_seconds;
     out->block_threads = m.plan_threads; out->group_slices = m.plan_group; out->lds_bytes = m.plan_lds * 4;
     out->col_tiles = (int32_t)m.parts.size();
-    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->reserved = 0;
+    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width;
     return HISPMV_OK;
 }
 

@@ -74,7 +74,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
 // No global store sits between a slice's loads, so hipcc keeps them all in flight together.
 // ---------------------------------------------------------------------------
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
-__global__ __launch_bounds__(512) void spmv_slices_kernel(
+__global__ __launch_bounds__(1024) void spmv_slices_kernel(
     const uint4* __restrict__ words, const int4* __restrict__ hdr, const int2* __restrict__ groups,
     const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,

@@ -124,7 +124,7 @@ typedef struct hispmv_matrix_info {
     int32_t lds_bytes;      /*   LDS bytes of the x window (0 = x gathered through L2) */
     int32_t col_tiles;      /* number of column tiles (1 = untiled) */
     int32_t carry_lookback; /* 1 = rows shared between slices are merged inside the launch (look-back), 0 = fix-up launch */
-    int32_t reserved;
+    int32_t col_tile_width; /* columns per tile when col_tiles > 1, else 0 */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);

@@ -27,6 +27,21 @@ def fpga(pyhispmv_mod):
     h.close()
 
 
+def emulate_device(info, r, c, v, rows, cols, x, b, alpha, beta):
+    """The wavefront model applied the way the device runs the handle: one stream per column tile (tile 0
+    with beta*bias, later tiles accumulating in place), carry variant as reported by matrix_info."""
+    from hispmv_amd.prep import prep_from_coo
+    r, c, v = np.asarray(r), np.asarray(c), np.asarray(v, np.float32)
+    width = info["col_tile_width"] if info["col_tiles"] > 1 else cols
+    ye = None
+    for t in range(info["col_tiles"]):
+        sel = (c >= t * width) & (c < (t + 1) * width)
+        P = prep_from_coo(r[sel], c[sel], v[sel], rows, cols)
+        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b if t == 0 else ye, alpha, beta if t == 0 else 1.0, rows,
+                             info["carry_lookback"])
+    return ye
+
+
 def csr_truth(r, c, v, rows, x, b, alpha, beta):
     order = np.lexsort((c, r))
     rp = np.zeros(rows + 1, np.int64)
@@ -61,7 +76,8 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
     assert pl < 1e-5
     # the CPU model of the wavefront performs the same fp32 operations in the same order
     P = prep_from_mtx(GOLDEN / f"{name}.mtx", 1)
-    ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, y0, ALPHA, BETA, rows, fpga.matrix_info(idx)["carry_lookback"])
+    rr = np.repeat(np.arange(rows, dtype=np.int32), np.diff(P.row_ptr))
+    ye = emulate_device(fpga.matrix_info(idx), rr, P.col_idx, P.values, rows, cols, x, y0, ALPHA, BETA)
     assert np.array_equal(y.view(np.uint32), ye.view(np.uint32)), "GPU result differs bitwise from the wavefront model"
     info = fpga.matrix_info(idx)
     assert info["nnz"] == g["ref_col_idx"].size and info["loaded"] == 1 and not info["is_dense"]
@@ -88,16 +104,15 @@ def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypat
     h.load_matrices()
     h.select_matrix(idx)
     P = prep_from_coo(r, c, v, rows, cols)
-    if mode is None:
-        mode = h.matrix_info(idx)["carry_lookback"]
-    else:
-        assert h.matrix_info(idx)["carry_lookback"] == mode
+    info = h.matrix_info(idx)
+    if mode is not None:
+        assert info["carry_lookback"] == mode
     y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, ALPHA, BETA)
+    ye = emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA)
     for _ in range(3):                      # repeated launches reuse the granules with a new launch tag
         y = np.full(rows, np.nan, np.float32)
         h.run_kernel(x, b, y, ALPHA, BETA)
         assert bwd_err(y, y64, mag) < TOL
-        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, ALPHA, BETA, rows, mode)
         assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
     h.close()
 
@@ -117,20 +132,13 @@ def test_column_tiled_scattered_matrix(fpga):
     idx = fpga.create_sparse_handle(r, c, v, rows, cols)
     fpga.load_matrices()
     info = fpga.matrix_info(idx)
-    tiles = -(-cols * 4 // (4 << 20))
-    width = (-(-cols // tiles) + 63) & ~63
-    assert info["col_tiles"] == -(-cols // width) == 2 and info["lds_bytes"] == 0
+    assert info["col_tiles"] == 2 and info["lds_bytes"] == 0 and info["col_tile_width"] % 64 == 0
     y = np.zeros(rows, np.float32)
     fpga.select_matrix(idx)
     fpga.run_kernel(x, b, y, ALPHA, BETA)
     y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
     assert bwd_err(y, y64, mag) < TOL
-    ye = None
-    for t in range(info["col_tiles"]):
-        sel = (c >= t * width) & (c < (t + 1) * width)
-        P = prep_from_coo(r[sel], c[sel], v[sel], rows, cols)
-        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b if t == 0 else ye, ALPHA, BETA if t == 0 else 1.0, rows, info["carry_lookback"])
-    assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
+    assert np.array_equal(y.view(np.uint32), emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA).view(np.uint32))
 
 
 def test_general_test_call_sequence_scaled(fpga):
