@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-matrix-reps", type=int, default=10)
     ap.add_argument("--details", type=str, default="", help="write the per-matrix table to this JSON file")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the SpMVs of a step are spread over (independent matrices may overlap)")
     ap.add_argument("--standin", choices=["structured", "uniform"], default="structured",
                     help="stand-in family of the mesh-origin matrices: structured FEM-like (default) or unstructured band")

@@ -157,6 +157,7 @@ GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus, int32_t rows)
         {256, 8, 6 * 1024, 4},             // small windows: many small workgroups
         {512, 16, 12 * 1024, 2},
         {512, 0, 12 * 1024, 2},            // persistent: 2 workgroups per CU, window staged once per workgroup
+        {512, 16, kMaxLdsFloats, 1},       // mid-size matrices with a large window: 8 wavefronts per CU
         {1024, 64, kMaxLdsFloats, 1},
         {1024, 0, kMaxLdsFloats, 1},       // persistent: 1 workgroup (16 wavefronts) per CU
     };
@@ -296,6 +297,17 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
             m->parts.emplace_back();
             m->parts.back().st = build_stream(column_tile(csr, c0, std::min<int64_t>((int64_t)c0 + tw, csr.cols)));
             finish_part(m->parts.back(), c->n_cus);
+        }
+        // two tiles were meant to bring the x window into LDS: if they still gather through L2, tiling only
+        // costs a launch and a read-modify-write of y -- go back to the single stream
+        bool lds_goal = csr.cols <= 2 * kMaxLdsFloats, all_lds = true;
+        for (auto& p : m->parts) all_lds = all_lds && p.plan.lds_floats > 0;
+        if (lds_goal && !all_lds) {
+            m->parts.clear();
+            m->col_tile_width = 0;
+            m->parts.emplace_back();
+            m->parts[0].st = build_stream(csr);
+            finish_part(m->parts[0], c->n_cus);
         }
     }
     csr = Csr{};
