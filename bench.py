@@ -223,7 +223,7 @@ def main():
     # per-matrix table (outside the timed region): events around `reps` launches of one matrix; the
     # other matrices are touched in between so that each measurement starts from a cold Infinity Cache
     table = []
-    if rank == 0:
+    if rank == 0 and args.per_matrix_reps > 0:
         big = max(mats, key=lambda q: q["device_bytes"])
         for m in mats:
             ts = []
@@ -252,6 +252,17 @@ def main():
         achieved = bytes_step * args.steps / t_dev / 1e9          # per GPU, device time
         launches = len(mats) * args.steps
         geo = math.exp(sum(math.log(r["gflops"]) for r in table) / len(table)) if table else None
+        # HBM traffic per launch from the PMC passes of tools/profile_round.sh (same command under rocprofv3;
+        # FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), if a summary has been committed
+        traffic, traffic_src = None, None
+        cands = sorted((ROOT / "profiles").glob("*_traffic.json"), key=lambda q: q.stat().st_mtime)
+        if cands and world == 1 and not names:
+            try:
+                tj = json.loads(cands[-1].read_text())
+                traffic = int(tj["hbm_bytes_per_step"] / max(1, len(mats)))
+                traffic_src = f"profiles/{cands[-1].name}"
+            except Exception:
+                traffic = None
         out = {
             "metric": "SpMV GFLOP/s, SuiteSparse set (20 matrices), fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
             "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -267,7 +278,7 @@ def main():
             "geomean_gflops_per_matrix": None if geo is None else round(geo, 2),
             "roofline": {"bound": "hbm", "kernel": "spmv_slices_kernel (+ carry fix-up launches)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch_avg": int(bytes_step / len(mats)),
                          "avg_launch_us": round(t_dev / launches * 1e6, 3),
                          "note": "achieved = sum over the set of (8*nnz+16*rows+4) B / HIP-event time of the timed region on the launch stream"},

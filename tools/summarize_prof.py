@@ -66,6 +66,14 @@ if fetch or write:
         traffic[n[:60]] = {"launches": fetch[1].get(n, 0) if fetch else 0, "read_bytes_per_launch": fk * 1024 * 2, "write_bytes_per_launch": wk * 1024}
         out.append(f"| `{n[:60]}` | {fetch[1].get(n, 0) if fetch else 0} | {fk:.0f} | {fk*1024*2/1e6:.2f} | {wk*1024/1e6:.2f} |")
     out.append("")
+PASSES = 6    # tools/profile_round.sh: --warmup 1 --steps 5, no per-matrix pass
+tot_r = sum(v["read_bytes_per_launch"] * v["launches"] for v in traffic.values())
+tot_w = sum(v["write_bytes_per_launch"] * v["launches"] for v in traffic.values())
+summary = {"passes": PASSES, "hbm_read_bytes_per_step": tot_r / PASSES, "hbm_write_bytes_per_step": tot_w / PASSES,
+           "hbm_bytes_per_step": (tot_r + tot_w) / PASSES, "kernels": traffic,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 (gfx950)"}
+out += [f"HBM traffic per step (one pass over the 20 matrices): read {tot_r / PASSES / 1e6:.1f} MB + write {tot_w / PASSES / 1e6:.1f} MB "
+        f"= {(tot_r + tot_w) / PASSES / 1e6:.1f} MB; algorithmic bytes per step: 1421.1 MB.", ""]
 (dst / f"{tag}_summary.md").write_text("\n".join(out) + "\n")
-(dst / f"{tag}_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+(dst / f"{tag}_traffic.json").write_text(json.dumps(summary, indent=1) + "\n")
 print("\n".join(out))
