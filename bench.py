@@ -66,9 +66,17 @@ def load_set(names, rank, world, uniform=False):
         if real is not None and world == 1:
             out.append(dict(name=name, source="file:" + str(real), path=str(real)))
             continue
-        seed = zlib.crc32(name.encode()) + rank       # rank k's block of the N-fold scaled matrix
-        rp, ci, va, used = M.make_standin(name, rows, nnz, fam, par, seed, uniform)
-        out.append(dict(name=name, source=f"synthetic:{used}", rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
+        seed = zlib.crc32(name.encode())
+        rp, ci, va, used = M.make_standin(name, rows, nnz, fam, par, seed + rank, uniform)
+        if world == 1:
+            out.append(dict(name=name, source=f"synthetic:{used}", rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
+            continue
+        # N-fold scaled matrix = `world` stacked blocks; this rank's shard is cut inside rows on both sides
+        from hispmv_amd.dist import shard_of_stacked_blocks
+        nxt = M.make_standin(name, rows, nnz, fam, par, seed + rank + 1, uniform)[:3] if rank + 1 < world else None
+        sh = shard_of_stacked_blocks((rp, ci, va), nxt, rows, rows, rank, world)
+        out.append(dict(name=name, source=f"synthetic:{used}", rows=sh.n_rows, cols=rows * world, nnz=int(sh.row_ptr[-1]),
+                        rp=sh.row_ptr, ci=sh.col_idx, va=sh.values, shard=sh))
     return out
 
 
@@ -130,11 +138,19 @@ def main():
     import pyhispmv
     from hispmv_amd import matrices as M
 
+    # HISPMV_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- rehearses the N > 1 code path on a
+    # one-GPU box (numbers from such a run mean nothing)
+    rehearsal = os.environ.get("HISPMV_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     names = [n for n in args.matrices.split(",") if n]
     t0 = time.time()
@@ -161,6 +177,8 @@ def main():
         m["x"] = torch.rand(m["cols"], generator=g, dtype=torch.float32).to(dev)
         m["b"] = torch.rand(m["rows"], generator=g, dtype=torch.float32).to(dev)
         m["y"] = torch.zeros(m["rows"], dtype=torch.float32, device=dev)
+        if m.get("shard") is not None and m["shard"].tail_open:
+            m["b"][-1] = 0.0        # the cut row belongs to the next rank: this rank only contributes alpha*partial
 
     # a dedicated (non-default) HIP stream: every launch, event and collective of the timed region is on it
     stream = torch.cuda.Stream(device=dev)

@@ -79,6 +79,43 @@ def shard_csr(row_ptr, col_idx, values, world: int, rank: int) -> Shard:
                  np.asarray(values)[idx].astype(np.float32), bool(eoff[r0] < b), bool(eoff[r1] > e))
 
 
+def shard_of_stacked_blocks(cur, nxt, rows: int, cols: int, rank: int, world: int) -> Shard:
+    """Weak-scaling workload of bench.py: the global matrix is `world` row blocks stacked (block b = the base
+    matrix generated with seed+b, its columns shifted by b*cols; x is replicated), and rank k owns the element
+    range of block k shifted by `delta` elements, so that every rank boundary cuts through a row and the
+    boundary exchange carries real partial sums.  Rank k therefore needs block k and the first rows of block
+    k+1 only.  cur / nxt = (row_ptr, col_idx, values) of blocks rank and rank+1 (nxt None on the last rank)."""
+    def cut_of(rp):                      # a cut in the middle of the first row (after row 3) with >= 2 elements
+        lens = np.diff(rp)
+        cand = np.nonzero(lens[4:] >= 2)[0]
+        r = int(cand[0]) + 4 if cand.size else 0
+        return (int(rp[r] + lens[r] // 2), r) if lens[r] >= 2 else (0, 0)
+    rp, ci, va = (np.asarray(a) for a in cur)
+    d0, r0 = cut_of(rp) if rank > 0 else (0, 0)           # this block's first d0 elements belong to rank-1
+    row_ptr = [np.asarray(rp[r0:], dtype=np.int64) - d0]
+    row_ptr[0][0] = 0
+    cols_l = [ci[d0:].astype(np.int64) + rank * cols]
+    vals_l = [va[d0:]]
+    head_open = rank > 0 and d0 > rp[r0]
+    tail_open = False
+    n_rows = rows - r0
+    if nxt is not None:
+        rp2, ci2, va2 = (np.asarray(a) for a in nxt)
+        d1, r1 = cut_of(rp2)
+        if d1 > 0:
+            ext = np.asarray(rp2[1:r1 + 1], dtype=np.int64)
+            ext = np.concatenate([ext, [d1]]) if d1 > rp2[r1] else ext
+            row_ptr.append(ext + row_ptr[0][-1])
+            cols_l.append(ci2[:d1].astype(np.int64) + (rank + 1) * cols)
+            vals_l.append(va2[:d1])
+            tail_open = d1 > rp2[r1]
+            n_rows += ext.size
+    rp_loc = np.concatenate(row_ptr)
+    return Shard(rank, world, 0, int(rp_loc[-1]), rank * rows + r0, int(n_rows), rp_loc.astype(np.int32),
+                 np.concatenate(cols_l).astype(np.int32), np.concatenate(vals_l).astype(np.float32),
+                 bool(head_open), bool(tail_open))
+
+
 def chain_weights(flags: np.ndarray, rank: int) -> np.ndarray:
     """flags[world, 3] = (head_open, tail_open, single_row) of one matrix on every rank.  Returns
     w[world] in {0,1}: the ranks whose tails are parts of this rank's first row -- rank-1 if its tail is

@@ -116,3 +116,36 @@ def test_shards_cover_matrix_exactly():
             tot += sh.values.size
             assert sh.row_ptr[-1] == sh.values.size == sh.col_idx.size
         assert tot == m["va"].size
+
+
+def test_stacked_block_shards_cut_rows_and_reassemble():
+    """bench.py's weak-scaling workload: `world` stacked blocks, every rank boundary inside a row."""
+    import zlib
+    from hispmv_amd import matrices as M
+    from hispmv_amd.dist import shard_of_stacked_blocks
+    name, rows, nnz, fam, par = [t for t in M.SUITESPARSE_SET if t[0] == "ford2"][0]
+    world, seed = 3, zlib.crc32(name.encode())
+    blocks = [M.make_standin(name, rows, nnz, fam, par, seed + k)[:3] for k in range(world)]
+    offs = np.cumsum([0] + [int(b[0][-1]) for b in blocks])
+    rp = np.concatenate([[0]] + [b[0][1:].astype(np.int64) + offs[k] for k, b in enumerate(blocks)])
+    ci = np.concatenate([b[1].astype(np.int64) + k * rows for k, b in enumerate(blocks)])
+    va = np.concatenate([b[2] for b in blocks])
+    rng = np.random.default_rng(0)
+    x = rng.random(world * rows).astype(np.float32)
+    bias = rng.random(world * rows).astype(np.float32)
+    y64, mag = oracle.spmv_f64(rp.astype(np.int32), ci.astype(np.int32), va, x, bias, 0.55, -2.05)
+    sh = [shard_of_stacked_blocks(blocks[k], blocks[k + 1] if k + 1 < world else None, rows, rows, k, world) for k in range(world)]
+    assert [s.head_open for s in sh] == [False, True, True] and [s.tail_open for s in sh] == [True, True, False]
+    assert sum(s.values.size for s in sh) == va.size
+    flags = np.array([[s.head_open, s.tail_open, s.n_rows == 1] for s in sh], np.float32)
+    ys = [oracle.cpu_spmv(s.row_ptr, s.col_idx, s.values, x, s.local_bias(bias), 0.55, -2.05, 1) for s in sh]
+    tails = np.array([y[-1] if s.tail_open else 0.0 for y, s in zip(ys, sh)])
+    Y = np.full(world * rows, np.nan)
+    for k, s in enumerate(sh):
+        y = ys[k].copy()
+        if s.head_open:
+            y[0] += float((chain_weights(flags, k) * tails).sum())
+        n = s.n_rows - (1 if s.tail_open else 0)
+        assert np.isnan(Y[s.row_begin:s.row_begin + n]).all()
+        Y[s.row_begin:s.row_begin + n] = y[:n]
+    assert not np.isnan(Y).any() and bwd_err(Y, y64, mag) < 1e-5
