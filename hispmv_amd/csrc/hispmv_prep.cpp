@@ -8,6 +8,9 @@
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace hispmv {
 
@@ -118,14 +121,44 @@ Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const 
         bad = bad || (r[i] < 0 || r[i] >= rows || c[i] < 0 || c[i] >= cols);
     if (bad) throw std::out_of_range("COO index outside matrix dimensions");
 
-    for (int64_t i = 0; i < nnz; ++i) m.row_ptr[(size_t)r[i] + 1]++;
-    for (int32_t i = 0; i < rows; ++i) m.row_ptr[(size_t)i + 1] += m.row_ptr[i];
-    {
+    // Stable counting sort by row, parallel over ROW RANGES: every thread streams the whole COO once and
+    // takes the entries of its own rows (input order inside a row is kept; the random writes of a thread stay
+    // inside its block of the output).  The reference does this step serially with a vector per (tile,row)
+    // (spmv-helper.cpp:139-227), ~87 % of its preprocessing time.
+    int nt = 1;
+#ifdef _OPENMP
+    nt = std::max(1, omp_get_max_threads());
+#endif
+    nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, nnz / (1 << 20)));
+    if (nt <= 1) {
+        for (int64_t i = 0; i < nnz; ++i) m.row_ptr[(size_t)r[i] + 1]++;
+        for (int32_t i = 0; i < rows; ++i) m.row_ptr[(size_t)i + 1] += m.row_ptr[i];
         std::vector<int64_t> cur(m.row_ptr.begin(), m.row_ptr.end() - 1);
         for (int64_t i = 0; i < nnz; ++i) {
             int64_t k = cur[r[i]]++;
             m.col[k] = c[i];
             m.val[k] = v[i];
+        }
+    } else {
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const int32_t r0 = (int32_t)((int64_t)rows * t / nt), r1 = (int32_t)((int64_t)rows * (t + 1) / nt);
+            for (int64_t i = 0; i < nnz; ++i) { const int32_t ri = r[i]; if (ri >= r0 && ri < r1) m.row_ptr[(size_t)ri + 1]++; }
+        }
+        for (int32_t i = 0; i < rows; ++i) m.row_ptr[(size_t)i + 1] += m.row_ptr[i];
+        std::vector<int64_t> cur(m.row_ptr.begin(), m.row_ptr.end() - 1);
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const int32_t r0 = (int32_t)((int64_t)rows * t / nt), r1 = (int32_t)((int64_t)rows * (t + 1) / nt);
+            for (int64_t i = 0; i < nnz; ++i) {
+                const int32_t ri = r[i];
+                if (ri < r0 || ri >= r1) continue;
+                const int64_t k = cur[ri]++;
+                m.col[k] = c[i];
+                m.val[k] = v[i];
+            }
         }
     }
     // stable sort by column inside each row (rows already ascending are skipped)
