@@ -714,6 +714,16 @@ HISPMV_API int hispmv_prep_dims(const hispmv_prep* p, int64_t d[8]) {
     d[5] = kSliceElems; d[6] = (int64_t)p->st.fix.size(); d[7] = p->st.bytes();
     return HISPMV_OK;
 }
+HISPMV_API int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]) {
+    if (!p || !plan || n_cus <= 0) return HISPMV_EINVAL;
+    const GroupPlan g = plan_groups(p->st.hdr, n_cus, p->st.rows);
+    const int ytile = ytile_floats_for(p->st.hdr, p->st.rows);
+    plan[0] = g.block_threads; plan[1] = g.group_slices; plan[2] = g.lds_floats; plan[3] = ytile;
+    plan[4] = (p->st.n_slices + g.group_slices - 1) / std::max(1, g.group_slices);
+    plan[5] = ((int64_t)g.lds_floats + (int64_t)ytile * (g.block_threads / 64)) * 4;
+    return HISPMV_OK;
+}
+
 HISPMV_API const int64_t* hispmv_prep_csr_row_ptr(const hispmv_prep* p) { return p->csr.row_ptr.data(); }
 HISPMV_API const int32_t* hispmv_prep_csr_col(const hispmv_prep* p) { return p->csr.col.data(); }
 HISPMV_API const float* hispmv_prep_csr_val(const hispmv_prep* p) { return p->csr.val.data(); }

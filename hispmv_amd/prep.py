@@ -27,6 +27,7 @@ class Prepared:
     words: np.ndarray      # uint64 [n_slices*slice_elems]: low 32 = fp32 bits, high 32 = rowEnd<<31 | col
     hdr: np.ndarray        # int32 [n_slices,4]: row_base, chain_len, x_base, x_span
     fix: np.ndarray        # int32 [n_split,4]: row, first_slice, len, 0
+    plan: dict = None      # launch plan on a 256-CU device: threads, group_slices, lds_floats, ytile_floats, groups, lds_bytes
 
 
 def _collect(p) -> Prepared:
@@ -47,6 +48,9 @@ def _collect(p) -> Prepared:
                    arr(lib.hispmv_prep_words(p), n_slices * se),
                    arr(lib.hispmv_prep_slice_hdr(p), n_slices * 4, (-1, 4)),
                    arr(lib.hispmv_prep_fix(p), n_fix * 4, (-1, 4)))
+    pl = (C.c_int64 * 6)()
+    if lib.hispmv_prep_plan(p, 256, pl) == HISPMV_OK:
+        out.plan = dict(zip(("threads", "group_slices", "lds_floats", "ytile_floats", "groups", "lds_bytes"), (int(v) for v in pl)))
     lib.hispmv_prep_free(p)
     return out
 

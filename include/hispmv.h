@@ -147,6 +147,11 @@ const uint64_t* hispmv_prep_words(const hispmv_prep* p);     /* n_slices * slice
 const int32_t* hispmv_prep_slice_hdr(const hispmv_prep* p);   /* n_slices x {row_base, chain_len, x_base, x_span} */
 const int32_t* hispmv_prep_fix(const hispmv_prep* p);         /* n_split_rows x {row, first_slice, len, 0} */
 
+/* Launch plan the loader would choose for this stream on a device with n_cus compute units (host-only, no
+ * device needed): plan[0..5] = workgroup threads, slices per workgroup, x-window LDS floats, row-total LDS
+ * floats per wavefront, workgroups, total dynamic LDS bytes per workgroup. */
+int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
+
 /* Library identification: "hispmv-amd <version> gfx950". */
 const char* hispmv_version(void);
 

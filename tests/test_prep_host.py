@@ -183,3 +183,25 @@ def test_property_random_coo_matches_scipy(rows, cols, nnz, seed):
     y = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, 2.0, -1.0, rows)
     ref = 2.0 * (sp.coo_matrix((v.astype(np.float64), (r, c)), shape=(rows, cols)) @ x.astype(np.float64)) - b
     assert np.array_equal(y.astype(np.float64), ref)
+
+
+def test_launch_plans_respect_the_lds_of_a_cu():
+    """Every plan the loader can choose fits the 160 KiB LDS of a CU (x window + row-total tiles of all its
+    wavefronts), for matrix shapes that stress each side of the budget."""
+    rng = np.random.default_rng(5)
+    shapes = []
+    n = 200000
+    shapes.append((rng.integers(0, n, 800000), rng.integers(0, n, 800000), n, n))                       # scattered, short rows
+    r = rng.integers(0, 3000, 600000); shapes.append((r, (r * 7 + rng.integers(0, 300, r.size)) % 30000, 3000, 30000))   # long rows, narrow band
+    w = 1.0 / (np.arange(60000) + 1.0) ** 1.2
+    shapes.append((rng.choice(60000, 1500000, p=w / w.sum()), rng.integers(0, 50000, 1500000), 60000, 50000))            # power law, many empty rows
+    r = np.repeat(np.arange(40000), 30); shapes.append((r, (r + rng.integers(-500, 500, r.size)) % 40000, 40000, 40000))  # band
+    r = rng.integers(0, 500000, 500000); shapes.append((r, rng.integers(0, 5000, r.size), 500000, 5000))                  # ~1 nnz per row: 1024 rows per slice
+    for r, c, rows, cols in shapes:
+        P = prep_from_coo(r, c, np.ones(r.size, np.float32), rows, cols)
+        pl = P.plan
+        assert pl["threads"] in (256, 512, 1024) and pl["group_slices"] >= 1
+        assert pl["lds_bytes"] <= 160 * 1024 - 512, pl
+        per_slice_rows = np.diff(np.concatenate([P.hdr[:, 0], [rows]]))
+        assert pl["ytile_floats"] >= per_slice_rows.max() and pl["ytile_floats"] <= 1024
+        assert pl["groups"] * pl["group_slices"] >= P.n_slices

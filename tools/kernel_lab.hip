@@ -38,6 +38,11 @@ __device__ __forceinline__ float wave_total(float v) {   // plain DPP reduction,
     v += i2f(__builtin_amdgcn_update_dpp(0, f2i(v), 0x143, 0xc, 0xf, false));
     return i2f(__builtin_amdgcn_readlane(f2i(v), 63));
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ntload(const uint4* p) {
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return uint4{v.x, v.y, v.z, v.w};
+}
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -45,8 +50,8 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
 // SCAN: 0 none (sum only), 1 full segmented scan every step, 2 plain reduction when the step has no row end
 // OUT : 0 no bias/y traffic, 1 full output
 // LDS : x window of the whole chunk in LDS (staged once), else buffer gathers
-template <int SCAN, int OUT, bool LDS, bool PIPE>
-__global__ __launch_bounds__(512) void lab_kernel(const uint4* __restrict__ words, const int4* __restrict__ hdr,
+template <int SCAN, int OUT, bool LDS, bool PIPE, bool NT = false>
+__global__ __launch_bounds__(1024) void lab_kernel(const uint4* __restrict__ words, const int4* __restrict__ hdr,
                                                   const float* __restrict__ x, const float* bias, float* y,
                                                   float* __restrict__ carry, float alpha, float beta,
                                                   long long n_slices, int group_slices, int x_base, int x_span, int cols, int rows) {
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(512) void lab_kernel(const uint4* __restrict__ word
     if (slice < last) {
         const uint4* p = words + slice * (kSliceElems / 2) + lane;
 #pragma unroll
-        for (int j = 0; j < kSliceSteps; ++j) w[j] = p[j * 64];
+        for (int j = 0; j < kSliceSteps; ++j) w[j] = NT ? ntload(p + j * 64) : p[j * 64];
         h = hdr[slice];
     }
     if (LDS) {
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(512) void lab_kernel(const uint4* __restrict__ word
         if (PIPE && slice < last) {
             const uint4* p = words + slice * (kSliceElems / 2) + lane;
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) w[j] = p[j * 64];
+            for (int j = 0; j < kSliceSteps; ++j) w[j] = NT ? ntload(p + j * 64) : p[j * 64];
             h = hdr[slice];
         }
         float t0[kSliceSteps], t1[kSliceSteps];
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(512) void lab_kernel(const uint4* __restrict__ word
         if (!PIPE && slice < last) {
             const uint4* p = words + slice * (kSliceElems / 2) + lane;
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) w[j] = p[j * 64];
+            for (int j = 0; j < kSliceSteps; ++j) w[j] = NT ? ntload(p + j * 64) : p[j * 64];
             h = hdr[slice];
         }
     }
@@ -196,12 +201,12 @@ static Mat make(int rows, int cols, int row_len, int band, int run, unsigned see
     return d;
 }
 
-template <int SCAN, int OUT, bool LDS, bool PIPE>
-static float run(const Mat& m, int threads, int per_cu, int reps) {
-    const int group = (int)((m.n_slices + 256LL * per_cu - 1) / (256LL * per_cu));
+template <int SCAN, int OUT, bool LDS, bool PIPE, bool NT = false>
+static float run(const Mat& m, int threads, int per_cu, int reps, int group_override = 0) {
+    const int group = group_override ? group_override : (int)((m.n_slices + 256LL * per_cu - 1) / (256LL * per_cu));
     const unsigned grid = (unsigned)((m.n_slices + group - 1) / group);
     const size_t lds = LDS ? (size_t)m.x_span * 4 : 0;
-    auto k = lab_kernel<SCAN, OUT, LDS, PIPE>;
+    auto k = lab_kernel<SCAN, OUT, LDS, PIPE, NT>;
     if (LDS) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, 0, (const uint4*)m.words, m.hdr, m.x, m.bias, m.y, m.carry, 0.5f, -2.f, m.n_slices, group, m.x_base, m.x_span, m.cols, m.rows);
@@ -214,7 +219,45 @@ static float run(const Mat& m, int threads, int per_cu, int reps) {
     return ms / reps;
 }
 
-int main() {
+static Mat make_stencil(int rows, int row_len, int band, int run, unsigned seed) {
+    std::mt19937 g(seed);
+    std::vector<int> off;
+    for (int k = 0; k < row_len; k += run) { int o = (int)(g() % (unsigned)(2 * band)) - band; for (int q = 0; q < run; ++q) off.push_back(o + q); }
+    std::sort(off.begin(), off.end()); off.erase(std::unique(off.begin(), off.end()), off.end());
+    Csr m; m.rows = rows; m.cols = rows; m.row_ptr.assign(rows + 1, 0);
+    for (int i = 0; i < rows; ++i) { int n = 0; for (int o : off) n += (i + o >= 0 && i + o < rows); m.row_ptr[i + 1] = m.row_ptr[i] + n; }
+    m.col.resize(m.row_ptr[rows]); m.val.resize(m.col.size());
+    for (int i = 0; i < rows; ++i) { int64_t k = m.row_ptr[i]; for (int o : off) if (i + o >= 0 && i + o < rows) { m.col[k] = i + o; m.val[k] = 1.0f + (g() % 7) * 0.125f; ++k; } }
+    SliceStream st = build_stream(m);
+    Mat d{}; d.n_slices = st.n_slices; d.rows = rows; d.cols = rows;
+    d.alg_bytes = 8.0 * m.nnz() + 16.0 * rows;
+    CK(hipMalloc(&d.words, st.words.size() * 8)); CK(hipMemcpy(d.words, st.words.data(), st.words.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d.hdr, st.hdr.size() * 16)); CK(hipMemcpy(d.hdr, st.hdr.data(), st.hdr.size() * 16, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d.x, rows * 4 + 64)); CK(hipMemset(d.x, 0, rows * 4 + 64));
+    CK(hipMalloc(&d.bias, rows * 4)); CK(hipMemset(d.bias, 0, rows * 4));
+    CK(hipMalloc(&d.y, rows * 4)); CK(hipMalloc(&d.carry, st.n_slices * 4));
+    d.x_base = 0; d.x_span = (rows + 3) & ~3;
+    return d;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) {   // second experiment: stencil-like (PFlow-like) matrix, L2 gathers with reuse between rows
+        Mat D = make_stencil(1000000, 50, 30000, 4, 5);
+        printf("== D stencil 50/row band 30000 run 4: slices %lld, alg %.0f MB\n", D.n_slices, D.alg_bytes / 1e6);
+        for (int round = 0; round < 2; ++round) {
+            auto rep = [&](const char* v, float ms) { printf("  r%d %-44s %8.1f us  %7.1f GB/s\n", round, v, ms * 1e3, D.alg_bytes / ms / 1e6); fflush(stdout); };
+            rep("glb full      256t 8 slices/WG", run<1, 1, false, true>(D, 256, 4, 5, 8));
+            rep("glb full NT   256t 8 slices/WG", run<1, 1, false, true, true>(D, 256, 4, 5, 8));
+            rep("glb full      512t 16 slices/WG", run<1, 1, false, true>(D, 512, 2, 5, 16));
+            rep("glb full      256t 4 slices/WG", run<1, 1, false, true>(D, 256, 4, 5, 4));
+            rep("glb full      256t x4/CU resident", run<1, 1, false, true>(D, 256, 4, 5));
+            rep("glb full      1024t x1/CU resident", run<1, 1, false, true>(D, 1024, 1, 5));
+            rep("glb scan0out0 256t 8 slices/WG", run<0, 0, false, true>(D, 256, 4, 5, 8));
+            rep("glb scan1out0 256t 8 slices/WG", run<1, 0, false, true>(D, 256, 4, 5, 8));
+            rep("glb nopipe    256t 8 slices/WG", run<1, 1, false, false>(D, 256, 4, 5, 8));
+        }
+        return 0;
+    }
     // long rows, narrow window (TSOPF-like), 3x the size so that launches do not live in the Infinity Cache
     Mat A = make(114360, 114360, 424, 2400, 8, 1);      // ~388 MB stream, window whole x = 457 KB -> global; see B
     Mat B = make(250000, 4096 * 4, 200, 8000, 4, 2);    // 400 MB stream, x = 64 KiB: whole x in LDS
