@@ -68,6 +68,9 @@ SIGNATURES = {
     "hispmv_prep_last_error": (C.c_char_p, []),
     "hispmv_prep_dims": (C.c_int, [_p, _i64p]),
     "hispmv_prep_plan": (C.c_int, [_p, C.c_int, _i64p]),
+    "hispmv_prep_apply_plan": (C.c_int, [_p, C.c_int, _i64p]),
+    "hispmv_prep_groups": (_i32p, [_p]),
+    "hispmv_prep_frags": (_i32p, [_p]),
     "hispmv_prep_csr_row_ptr": (_i64p, [_p]),
     "hispmv_prep_csr_col": (_i32p, [_p]),
     "hispmv_prep_csr_val": (_f32p, [_p]),

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "hispmv_kernels.h"
+#include "hispmv_plan.h"
 #include "hispmv_prep.h"
 
 #define HISPMV_API extern "C" __attribute__((visibility("default")))
@@ -25,12 +26,6 @@
 using namespace hispmv;
 
 namespace {
-
-// Launch geometry of one slice stream (see plan_groups below).
-struct GroupPlan {
-    int block_threads = 256, group_slices = 8, lds_floats = 0;
-    std::vector<int2> groups;
-};
 
 struct Matrix {
     bool dense = false;
@@ -46,7 +41,7 @@ struct Matrix {
     struct Part {
         SliceStream st;                            // host side (released after upload)
         std::vector<FixEntry> fix_short, fix_long;
-        GroupPlan plan;
+        LaunchPlan plan;
         SpmvDeviceMatrix dev;                      // device side
     };
     std::vector<Part> parts;
@@ -85,6 +80,7 @@ struct hispmv_ctx {
 struct hispmv_prep {
     Csr csr;
     SliceStream st;
+    LaunchPlan plan;
 };
 
 namespace {
@@ -119,99 +115,6 @@ int check_device_error(hispmv_ctx* c) {
         return fail(c, HISPMV_EDEVICE, "carry hand-off between slices timed out (lost or overlapping launch on one handle)");
     }
     return HISPMV_OK;
-}
-
-// Launch geometry of a sparse matrix: how many slices one workgroup owns, how many wavefronts it
-// has, and how much LDS holds its x window.  The MI355X analogue of the reference's per-matrix
-// configuration choice (automation_tool/src/dse.py:23-95 picks channel counts per matrix; here the
-// choice is the x-window policy): small windows -> many small workgroups per CU; large windows ->
-// one 16-wave workgroup per CU; windows that do not fit 160 KiB -> that group gathers x through L2.
-// Column window of the slices [s0, s1): {base aligned down to 4 floats, span}.
-static int2 window_of(const std::vector<SliceHdr>& hdr, int64_t s0, int64_t s1) {
-    int lo = INT32_MAX, hi = 0;
-    for (int64_t s = s0; s < s1; ++s) {
-        lo = std::min(lo, hdr[s].x_base);
-        hi = std::max(hi, hdr[s].x_base + hdr[s].x_span);
-    }
-    if (s1 <= s0) return int2{0, 0};
-    lo &= ~3;
-    return int2{lo, hi - lo};
-}
-
-// LDS floats one wavefront needs for the row totals of a slice: the largest number of rows ending in one slice.
-static int ytile_floats_for(const std::vector<SliceHdr>& hdr, int32_t rows) {
-    int max_rows = 1;
-    for (size_t sl = 0; sl < hdr.size(); ++sl)
-        max_rows = std::max(max_rows, (sl + 1 < hdr.size() ? hdr[sl + 1].row_base : rows) - hdr[sl].row_base);
-    return std::min(kSliceElems, (max_rows + 63) & ~63);
-}
-
-GroupPlan plan_groups(const std::vector<SliceHdr>& hdr, int n_cus, int32_t rows) {
-    const int64_t n = (int64_t)hdr.size();
-    const int ytile = ytile_floats_for(hdr, rows);
-    // threads per workgroup, slices per workgroup (0 = one chunk per resident workgroup), LDS cap (floats),
-    // resident workgroups per CU at that cap
-    struct Cfg { int threads, slices, cap, per_cu; };
-    const Cfg cfgs[] = {
-        // (caps leave room for the row-total tiles: up to 1024 floats per wavefront)
-        {256, 8, 6 * 1024, 4},             // small windows: many small workgroups
-        {512, 16, 12 * 1024, 2},
-        {512, 0, 12 * 1024, 2},            // persistent: 2 workgroups per CU, window staged once per workgroup
-        {512, 16, kMaxLdsFloats, 1},       // mid-size matrices with a large window: 8 wavefronts per CU
-        {1024, 64, kMaxLdsFloats, 1},
-        {1024, 0, kMaxLdsFloats, 1},       // persistent: 1 workgroup (16 wavefronts) per CU
-    };
-    GroupPlan best;
-    double best_cost = 1e300;
-    bool have = false;
-    const char* force = std::getenv("HISPMV_PLAN");          // experiments: "global" or an index into cfgs
-    const int only = (force && *force >= '0' && *force <= '9') ? std::atoi(force) : -1;
-    int cfg_index = -1;
-    for (const Cfg& c0 : cfgs) {
-        ++cfg_index;
-        if (force && (only < 0 || only != cfg_index)) continue;
-        Cfg c = c0;
-        // what is left of the CU's 160 KiB after the row-total tiles of the resident workgroups
-        c.cap = std::min(c.cap, ((160 * 1024 - 1024) / c.per_cu - ytile * (c.threads / 64) * 4) / 4);
-        if (c.cap < 256) continue;
-        int64_t G = c.slices;
-        if (c.threads == 1024 && G != 0 && n / G < 512) continue;   // big workgroups only when there are plenty
-        if (G == 0) {
-            G = (n + (int64_t)n_cus * c.per_cu - 1) / ((int64_t)n_cus * c.per_cu);
-            if (G < 24) continue;                           // too little work to be worth a resident grid
-        } else {
-            if (n / G < 1024 && G > 4) G /= 2;              // small matrices: more, smaller workgroups
-            if (n / G < 512 && G > 4) G /= 2;
-        }
-        const int64_t ng = (n + G - 1) / G;
-        std::vector<int2> groups((size_t)ng);
-        int64_t ok = 0, staged = 0;
-        int max_ok = 0;
-        for (int64_t g = 0; g < ng; ++g) {
-            groups[g] = window_of(hdr, g * G, std::min<int64_t>(n, (g + 1) * G));
-            if (groups[g].y <= c.cap) { ok++; max_ok = std::max(max_ok, groups[g].y); staged += groups[g].y; }
-        }
-        const double frac = ng ? (double)ok / (double)ng : 0.0;
-        if (frac < 0.9) continue;
-        // cost: x bytes staged into LDS relative to the stream bytes (L2 -> LDS is ~5x cheaper per byte than the
-        // HBM stream), plus a penalty for fewer than 16 resident wavefronts per CU
-        const int waves = c.per_cu * c.threads / 64;
-        const double cost = 0.2 * (double)staged * 4.0 / ((double)n * kSliceElems * 8.0) + 0.3 * std::max(0, 16 - waves) / 16.0;
-        if (cost < best_cost) {
-            best_cost = cost; have = true;
-            best.block_threads = c.threads; best.group_slices = (int)G;
-            best.lds_floats = (max_ok + 3) & ~3;
-            best.groups = std::move(groups);
-        }
-    }
-    if (!have) {   // scattered columns: plain L2 gathers, small workgroups
-        GroupPlan g;
-        g.block_threads = 256; g.group_slices = (n / 8 < 1024) ? 4 : 8; g.lds_floats = 0;
-        const int64_t ng = (n + g.group_slices - 1) / g.group_slices;
-        g.groups.assign((size_t)std::max<int64_t>(ng, 1), int2{0, 0});
-        return g;
-    }
-    return best;
 }
 
 void free_matrix_device(Matrix& m) {
@@ -269,7 +172,7 @@ int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
 
 void finish_part(Matrix::Part& p, int n_cus) {
     for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
-    p.plan = plan_groups(p.st.hdr, n_cus, p.st.rows);
+    p.plan = make_plan(p.st, n_cus);     // also rewrites the column field of LDS-staged groups
 }
 
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
@@ -313,7 +216,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
     csr = Csr{};
     for (auto& p : m->parts) {
         m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
-        m->device_bytes += sparse_device_bytes(p.st) + (int64_t)p.plan.groups.size() * 8;
+        m->device_bytes += sparse_device_bytes(p.st) + (int64_t)p.plan.groups.size() * 16 + (int64_t)p.plan.frags.size() * 16;
     }
     m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
     m->plan_lds = m->parts[0].plan.lds_floats;
@@ -511,9 +414,10 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         } else {
             for (auto& p : m.parts) {
                 const uint64_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
-                const int2* dg = nullptr;
+                const GroupDesc* dg = nullptr; const Frag* dfr = nullptr;
                 const int64_t ns = p.st.n_slices;
                 if ((rc = upload(c, m, p.plan.groups.data(), p.plan.groups.size(), &dg)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.plan.frags.data(), p.plan.frags.size(), &dfr)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.st.words.data(), p.st.words.size(), &dw)) != HISPMV_OK) return rc;
                 // device header: {row_base, chain_len, rows ending in the slice, 0} (the column window of a slice is
                 // only needed by the planner)
@@ -540,7 +444,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 m.allocs.push_back(ticket);
                 HIP_TRY(c, hipMemsetAsync(ticket, 0, sizeof(unsigned long long), c->stream));
                 SpmvDeviceMatrix& d = p.dev;
-                d.words = dw; d.hdr = (const int4*)dh; d.groups = dg;
+                d.words = dw; d.hdr = (const int4*)dh; d.groups = (const int4*)dg; d.frags = (const int4*)dfr;
                 d.fix_short = (const int4*)fs; d.fix_long = (const int4*)fl;
                 d.carry = (float*)carry; d.gran = (unsigned long long*)gran; d.ticket = (unsigned long long*)ticket;
                 d.err = c->d_err; d.launches = 0; d.ticket_launches = 0;
@@ -565,7 +469,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // host copies are no longer needed
-        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; }
+        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; p.plan.frags = {}; }
         m.dense_host = {};
         m.loaded = true;
     }
@@ -716,13 +620,22 @@ HISPMV_API int hispmv_prep_dims(const hispmv_prep* p, int64_t d[8]) {
 }
 HISPMV_API int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]) {
     if (!p || !plan || n_cus <= 0) return HISPMV_EINVAL;
-    const GroupPlan g = plan_groups(p->st.hdr, n_cus, p->st.rows);
-    const int ytile = ytile_floats_for(p->st.hdr, p->st.rows);
-    plan[0] = g.block_threads; plan[1] = g.group_slices; plan[2] = g.lds_floats; plan[3] = ytile;
-    plan[4] = (p->st.n_slices + g.group_slices - 1) / std::max(1, g.group_slices);
-    plan[5] = ((int64_t)g.lds_floats + (int64_t)ytile * (g.block_threads / 64)) * 4;
+    SliceStream copy = p->st;                      // make_plan rewrites the words of staged groups
+    const LaunchPlan g = make_plan(copy, n_cus);
+    plan[0] = g.block_threads; plan[1] = g.group_slices; plan[2] = g.lds_floats; plan[3] = g.ytile_floats;
+    plan[4] = (int64_t)g.groups.size();
+    plan[5] = ((int64_t)g.lds_floats + (int64_t)g.ytile_floats * (g.block_threads / 64)) * 4;
     return HISPMV_OK;
 }
+
+HISPMV_API int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[2]) {
+    if (!p || !counts || n_cus <= 0) return HISPMV_EINVAL;
+    p->plan = make_plan(p->st, n_cus);
+    counts[0] = (int64_t)p->plan.groups.size(); counts[1] = (int64_t)p->plan.frags.size();
+    return HISPMV_OK;
+}
+HISPMV_API const int32_t* hispmv_prep_groups(const hispmv_prep* p) { return (const int32_t*)p->plan.groups.data(); }
+HISPMV_API const int32_t* hispmv_prep_frags(const hispmv_prep* p) { return (const int32_t*)p->plan.frags.data(); }
 
 HISPMV_API const int64_t* hispmv_prep_csr_row_ptr(const hispmv_prep* p) { return p->csr.row_ptr.data(); }
 HISPMV_API const int32_t* hispmv_prep_csr_col(const hispmv_prep* p) { return p->csr.col.data(); }

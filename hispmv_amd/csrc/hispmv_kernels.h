@@ -11,7 +11,8 @@ struct SpmvDeviceMatrix {
     const int4* hdr = nullptr;          // n_slices x {row_base, chain_len, x_base, x_span}
     const int4* fix_short = nullptr;    // {row, first_slice, len, 0}, len <= kFixShortMax
     const int4* fix_long = nullptr;     // same, len > kFixShortMax
-    const int2* groups = nullptr;       // n_groups x {x_base (multiple of 4), x_span}: the x window of a workgroup
+    const int4* groups = nullptr;       // n_groups x {frag_begin, frag_count, lds_floats, 0}: the x fragments a workgroup stages
+    const int4* frags = nullptr;        // {col_start, len, lds_off, 0}
     float* carry = nullptr;             // n_slices: partial sum each slice hands to the next
     int64_t n_groups = 0;
     int32_t group_slices = 8;           // slices per workgroup
@@ -41,7 +42,6 @@ struct LookbackArgs {
 };
 
 constexpr int kFixShortMax = 32;
-constexpr int kMaxLdsFloats = 30 * 1024;          // largest x window (120 KiB): leaves room for the row-total tiles
 
 // Once per process/device before the first launch (raises the dynamic-LDS limit of the slice kernels).
 hipError_t prepare_spmv_kernels();

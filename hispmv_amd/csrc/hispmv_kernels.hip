@@ -75,7 +75,8 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
 // ---------------------------------------------------------------------------
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
 __global__ __launch_bounds__(1024) void spmv_slices_kernel(
-    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int2* __restrict__ groups,
+    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const int4* __restrict__ frags,
     const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
     int lds_floats, int ytile_floats, int cols, int rows, LookbackArgs lb) {
@@ -126,18 +127,27 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         h = hdr[slice];
     }
 
-    int x_base = 0;
+    // LoadB: stage the x fragments of this group (runs of 64-byte blocks its slices touch) into LDS; the
+    // words of a staged group already carry the index into this window instead of the column.
     bool in_lds = false;
     if (USE_LDS) {
-        const int2 g = groups[group];
-        x_base = g.x;
-        in_lds = g.y <= lds_floats;          // workgroup-uniform
-        if (in_lds) {
-            const int span4 = g.y >> 2;      // x_base is a multiple of 4 floats (host), x is 16-B aligned
-            const float4* src = (const float4*)(x + x_base);
-            for (int i = threadIdx.x; i < span4; i += blockDim.x) ((float4*)xs)[i] = src[i];
-            for (int i = (span4 << 2) + threadIdx.x; i < g.y; i += blockDim.x)
-                xs[i] = (x_base + i < cols) ? x[x_base + i] : 0.0f;
+        const int4 g = groups[group];
+        in_lds = g.y > 0;                    // workgroup-uniform; 0 fragments = this group gathers through L2
+        for (int f = wave; f < g.y; f += n_waves) {
+            const int4 fr = frags[g.x + f];  // {col_start, len, lds_off}: multiples of 16 floats
+            const float4* src = (const float4*)(x + fr.x);
+            float4* dst = (float4*)(xs + fr.z);
+            for (int i = lane; i < (fr.y >> 2); i += 64) {
+                // the last block of x may reach past cols: read it element-wise
+                if (fr.x + 4 * i + 3 < cols) dst[i] = src[i];
+                else {
+                    float4 v = float4{0.f, 0.f, 0.f, 0.f};
+                    if (fr.x + 4 * i + 0 < cols) v.x = x[fr.x + 4 * i + 0];
+                    if (fr.x + 4 * i + 1 < cols) v.y = x[fr.x + 4 * i + 1];
+                    if (fr.x + 4 * i + 2 < cols) v.z = x[fr.x + 4 * i + 2];
+                    dst[i] = v;
+                }
+            }
         }
         __syncthreads();
     }
@@ -170,8 +180,8 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         if (USE_LDS && in_lds) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                x0[j] = xs[(int)(w[j].y & ~kRowEndBit) - x_base];
-                x1[j] = xs[(int)(w[j].w & ~kRowEndBit) - x_base];
+                x0[j] = xs[w[j].y & ~kRowEndBit];
+                x1[j] = xs[w[j].w & ~kRowEndBit];
             }
         } else {
 #pragma unroll
@@ -305,7 +315,7 @@ static void launch_slices(const SpmvDeviceMatrix& m, const LookbackArgs& lb, con
                           float alpha, float beta, hipStream_t stream) {
     const size_t lds = ((USE_LDS ? (size_t)m.lds_floats : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float);
     hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS, LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
-                       (const uint4*)m.words, m.hdr, m.groups, x, bias, y, m.carry, alpha, beta,
+                       (const uint4*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
                        (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, lb);
 }
 

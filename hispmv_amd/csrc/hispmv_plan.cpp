@@ -1,0 +1,203 @@
+// hispmv_plan.cpp -- see hispmv_plan.h.  Host-only, OpenMP.
+#include "hispmv_plan.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+namespace hispmv {
+
+namespace {
+
+inline int32_t col_of(uint64_t w) { return (int32_t)((w >> 32) & 0x7fffffffu); }
+
+struct Cfg { int threads, slices, cap, per_cu; };   // slices == 0: one chunk per resident workgroup
+
+// Scratch of one thread: the distinct 64-byte blocks of x touched by a range of slices.
+struct BlockSet {
+    std::vector<uint8_t> seen;       // bitmap path: one byte per block of the dense span
+    std::vector<int32_t> table;      // hash path: open addressing, -1 = empty
+    std::vector<int32_t> used;       // hash slots to clear
+    std::vector<int32_t> blocks;     // result of collect(): sorted distinct block ids
+
+    // Number of distinct blocks touched by slices [s0, s1), or limit + 1 as soon as it exceeds `limit`.
+    // With `keep`, `blocks` holds them sorted (only meaningful when the result is <= limit).
+    int64_t collect(const SliceStream& st, int64_t s0, int64_t s1, int64_t limit, bool keep) {
+        int lo = INT32_MAX, hi = -1;
+        for (int64_t s = s0; s < s1; ++s) {
+            lo = std::min(lo, st.hdr[s].x_base);
+            hi = std::max(hi, st.hdr[s].x_base + st.hdr[s].x_span - 1);
+        }
+        if (hi < 0) { blocks.clear(); return 0; }
+        const int32_t b_lo = lo / kFragBlock, b_hi = hi / kFragBlock;
+        const int64_t span_blocks = (int64_t)b_hi - b_lo + 1;
+        const uint64_t* w = st.words.data() + s0 * kSliceElems;
+        const int64_t n = (s1 - s0) * kSliceElems;
+        int64_t count = 0;
+        if (span_blocks <= 8 * std::max<int64_t>(limit, 64)) {          // dense enough: bitmap, exact
+            seen.assign((size_t)span_blocks, 0);
+            for (int64_t i = 0; i < n; ++i) {
+                uint8_t& f = seen[(size_t)(col_of(w[i]) / kFragBlock - b_lo)];
+                count += (f == 0);
+                f = 1;
+            }
+            if (keep && count <= limit) {
+                blocks.clear();
+                for (int64_t b = 0; b < span_blocks; ++b) if (seen[(size_t)b]) blocks.push_back((int32_t)(b_lo + b));
+            }
+            return count <= limit ? count : limit + 1;
+        }
+        // scattered: hash set with early exit
+        size_t cap = 1024;
+        while (cap < (size_t)(4 * std::max<int64_t>(limit, 64))) cap <<= 1;
+        if (table.size() != cap) table.assign(cap, -1);
+        used.clear();
+        bool over = false;
+        for (int64_t i = 0; i < n && !over; ++i) {
+            const int32_t b = col_of(w[i]) / kFragBlock;
+            size_t h = ((uint32_t)b * 2654435761u) & (cap - 1);
+            while (table[h] != -1 && table[h] != b) h = (h + 1) & (cap - 1);
+            if (table[h] == -1) {
+                table[h] = b; used.push_back((int32_t)h);
+                if (++count > limit) over = true;
+            }
+        }
+        if (keep && !over) {
+            blocks.clear();
+            for (int32_t h : used) blocks.push_back(table[(size_t)h]);
+            std::sort(blocks.begin(), blocks.end());
+        }
+        for (int32_t h : used) table[(size_t)h] = -1;
+        return over ? limit + 1 : count;
+    }
+};
+
+}  // namespace
+
+int ytile_floats_for(const SliceStream& st) {
+    int max_rows = 1;
+    for (size_t sl = 0; sl < st.hdr.size(); ++sl)
+        max_rows = std::max(max_rows, (sl + 1 < st.hdr.size() ? st.hdr[sl + 1].row_base : st.rows) - st.hdr[sl].row_base);
+    return std::min(kSliceElems, (max_rows + 63) & ~63);
+}
+
+LaunchPlan make_plan(SliceStream& st, int n_cus) {
+    const int64_t n = st.n_slices;
+    LaunchPlan best;
+    best.ytile_floats = ytile_floats_for(st);
+    const int ytile = best.ytile_floats;
+    const Cfg cfgs[] = {
+        // (caps are what is left of the CU's 160 KiB after the row-total tiles of the resident workgroups)
+        {256, 8, 6 * 1024, 4},             // small windows: many small workgroups
+        {512, 16, 12 * 1024, 2},
+        {512, 0, 12 * 1024, 2},            // resident grid: 2 workgroups per CU, window staged once per workgroup
+        {512, 16, kMaxLdsFloats, 1},       // mid-size matrices with a large window: 8 wavefronts per CU
+        {1024, 64, kMaxLdsFloats, 1},
+        {1024, 0, kMaxLdsFloats, 1},       // resident grid: 1 workgroup (16 wavefronts) per CU
+    };
+    const char* force = std::getenv("HISPMV_PLAN");          // experiments: "global" or an index into cfgs
+    const int only = (force && *force >= '0' && *force <= '9') ? std::atoi(force) : -1;
+    double best_cost = 1e300;
+    bool have = false;
+    Cfg chosen{256, 8, 0, 4};
+    int64_t chosen_G = 8;
+    int cfg_index = -1;
+    for (const Cfg& c0 : cfgs) {
+        ++cfg_index;
+        if (force && (only < 0 || only != cfg_index)) continue;
+        // tiny matrices (< 4 MB of stream) are one latency chain long: staging a window adds two dependent
+        // loads (fragment table, x) in front of it and buys nothing -- x is gathered through L2
+        if (n < 512 && !force) break;
+        Cfg c = c0;
+        c.cap = std::min(c.cap, ((160 * 1024 - 1024) / c.per_cu - ytile * (c.threads / 64) * 4) / 4);
+        c.cap &= ~(kFragBlock - 1);
+        if (c.cap < 256) continue;
+        int64_t G = c.slices;
+        if (c.threads == 1024 && G != 0 && n / G < 512) continue;   // big workgroups only when there are plenty
+        if (G == 0) {
+            G = (n + (int64_t)n_cus * c.per_cu - 1) / ((int64_t)n_cus * c.per_cu);
+            if (G < 24) continue;                                   // too little work to be worth a resident grid
+        } else {
+            if (n / G < 1024 && G > 4) G /= 2;                      // small matrices: more, smaller workgroups
+            if (n / G < 512 && G > 4) G /= 2;
+        }
+        const int64_t ng = (n + G - 1) / G;
+        const int64_t limit = c.cap / kFragBlock;
+        int64_t ok = 0, staged_blocks = 0;
+#pragma omp parallel reduction(+ : ok, staged_blocks)
+        {
+            BlockSet bs;
+#pragma omp for schedule(dynamic, 16)
+            for (int64_t g = 0; g < ng; ++g) {
+                const int64_t k = bs.collect(st, g * G, std::min<int64_t>(n, (g + 1) * G), limit, false);
+                if (k <= limit) { ok++; staged_blocks += k; }
+            }
+        }
+        if ((double)ok < 0.9 * (double)ng) continue;
+        // cost: x bytes staged into LDS relative to the stream bytes (L2 -> LDS is ~5x cheaper per byte than the
+        // HBM stream), plus a penalty for fewer than 16 resident wavefronts per CU
+        const int waves = c.per_cu * c.threads / 64;
+        const double cost = 0.2 * (double)staged_blocks * kFragBlock * 4.0 / ((double)n * kSliceElems * 8.0) +
+                            0.3 * std::max(0, 16 - waves) / 16.0;
+        if (cost < best_cost) { best_cost = cost; have = true; chosen = c; chosen_G = G; }
+    }
+    if (!have) {   // scattered columns: plain L2 gathers, small workgroups
+        best.block_threads = 256; best.group_slices = (n / 8 < 1024) ? 4 : 8; best.lds_floats = 0; best.per_cu = 4;
+        const int64_t ng = (n + best.group_slices - 1) / best.group_slices;
+        best.groups.assign((size_t)std::max<int64_t>(ng, 1), GroupDesc{0, 0, 0, 0});
+        return best;
+    }
+
+    // Build the chosen plan: fragment lists, and the element words of staged groups rewritten to LDS indices.
+    const int64_t G = chosen_G, ng = (n + G - 1) / G, limit = chosen.cap / kFragBlock;
+    best.block_threads = chosen.threads; best.group_slices = (int)G; best.per_cu = chosen.per_cu;
+    best.groups.assign((size_t)ng, GroupDesc{0, 0, 0, 0});
+    std::vector<std::vector<Frag>> gfrags((size_t)ng);
+#pragma omp parallel
+    {
+        BlockSet bs;
+        std::vector<int32_t> rank_of;    // dense path: block - b_lo -> rank
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t g = 0; g < ng; ++g) {
+            const int64_t s0 = g * G, s1 = std::min<int64_t>(n, (g + 1) * G);
+            const int64_t k = bs.collect(st, s0, s1, limit, true);
+            if (k > limit || k == 0) continue;
+            const std::vector<int32_t>& blocks = bs.blocks;
+            // fragments = runs of consecutive blocks, split at kFragMaxLen
+            std::vector<Frag>& fr = gfrags[(size_t)g];
+            int32_t off = 0;
+            for (size_t i = 0; i < blocks.size();) {
+                size_t j = i + 1;
+                while (j < blocks.size() && blocks[j] == blocks[j - 1] + 1 && (int)(j - i) * kFragBlock < kFragMaxLen) ++j;
+                fr.push_back(Frag{blocks[i] * kFragBlock, (int32_t)(j - i) * kFragBlock, off, 0});
+                off += (int32_t)(j - i) * kFragBlock;
+                i = j;
+            }
+            best.groups[(size_t)g].lds_floats = off;
+            // rewrite the column field of the group's elements: column -> index in the staged window
+            uint64_t* w = st.words.data() + s0 * kSliceElems;
+            const int64_t ne = (s1 - s0) * kSliceElems;
+            for (int64_t i = 0; i < ne; ++i) {
+                const int32_t col = col_of(w[i]);
+                const int32_t b = col / kFragBlock;
+                const int32_t r = (int32_t)(std::lower_bound(blocks.begin(), blocks.end(), b) - blocks.begin());
+                const uint32_t idx = (uint32_t)r * kFragBlock + (uint32_t)(col % kFragBlock);
+                w[i] = (w[i] & 0x80000000ffffffffull) | ((uint64_t)idx << 32);
+            }
+        }
+    }
+    int max_lds = 0;
+    for (int64_t g = 0; g < ng; ++g) {
+        GroupDesc& d = best.groups[(size_t)g];
+        d.frag_begin = (int32_t)best.frags.size();
+        d.frag_count = (int32_t)gfrags[(size_t)g].size();
+        best.frags.insert(best.frags.end(), gfrags[(size_t)g].begin(), gfrags[(size_t)g].end());
+        max_lds = std::max(max_lds, d.lds_floats);
+        best.staged_floats += d.lds_floats;
+    }
+    best.lds_floats = (max_lds + 3) & ~3;
+    if (best.lds_floats == 0) best.lds_floats = kFragBlock;   // a plan with a window never reports 0
+    return best;
+}
+
+}  // namespace hispmv

@@ -1,0 +1,52 @@
+// hispmv_plan.h -- per-matrix launch plan of the slice kernel: how many slices a workgroup owns, how many
+// wavefronts it has, and which FRAGMENTS of x it stages in LDS.  The MI355X analogue of the reference's
+// per-matrix configuration search (automation_tool/src/dse.py:23-95 picks channel counts and window sizes
+// per matrix) and of its x window (LoadB fills a BRAM window per column tile, base_functions.cpp:105-150):
+// here the "window" of a workgroup is the set of 64-byte blocks of x its slices touch, staged as a list of
+// contiguous fragments; the element words of such a group carry the LDS index instead of the column.
+// Host-only code.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "hispmv_prep.h"
+
+namespace hispmv {
+
+constexpr int kFragBlock = 16;            // floats per x block (64 B: one cache-line sector)
+constexpr int kFragMaxLen = 2048;         // fragments longer than this are split so that wavefronts share the staging
+constexpr int kMaxLdsFloats = 30 * 1024;  // largest x window (120 KiB): leaves room for the row-total tiles
+
+struct GroupDesc {        // 16 B per workgroup
+    int32_t frag_begin;   // first fragment of the group in the fragment table
+    int32_t frag_count;   // 0: the group gathers x through L2 (its words keep global columns)
+    int32_t lds_floats;   // floats of x the group stages
+    int32_t pad;
+};
+
+struct Frag {             // 16 B
+    int32_t col_start;    // first column (multiple of kFragBlock)
+    int32_t len;          // floats (multiple of kFragBlock, <= kFragMaxLen)
+    int32_t lds_off;      // where it lands in the workgroup's window (multiple of kFragBlock)
+    int32_t pad;
+};
+
+struct LaunchPlan {
+    int block_threads = 256;
+    int group_slices = 8;
+    int lds_floats = 0;        // window floats reserved per workgroup (max over the staged groups); 0 = no LDS window
+    int ytile_floats = 64;     // row-total tile per wavefront
+    int per_cu = 4;            // resident workgroups per CU the plan was sized for
+    std::vector<GroupDesc> groups;
+    std::vector<Frag> frags;
+    int64_t staged_floats = 0; // sum over groups (diagnostics)
+};
+
+// Chooses the plan for `st` on a device with n_cus compute units and REWRITES the column field of the
+// elements of every LDS-staged group in st.words to the element's index in that group's window.
+LaunchPlan make_plan(SliceStream& st, int n_cus);
+
+// LDS floats one wavefront needs for the row totals of a slice (largest number of rows ending in one slice).
+int ytile_floats_for(const SliceStream& st);
+
+}  // namespace hispmv

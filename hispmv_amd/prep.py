@@ -28,6 +28,9 @@ class Prepared:
     hdr: np.ndarray        # int32 [n_slices,4]: row_base, chain_len, x_base, x_span
     fix: np.ndarray        # int32 [n_split,4]: row, first_slice, len, 0
     plan: dict = None      # launch plan on a 256-CU device: threads, group_slices, lds_floats, ytile_floats, groups, lds_bytes
+    staged_words: np.ndarray = None   # the stream as the device gets it: staged groups carry window indices, not columns
+    groups: np.ndarray = None         # int32 [n_groups,4]: frag_begin, frag_count, lds_floats, 0
+    frags: np.ndarray = None          # int32 [n_frags,4]: col_start, len, lds_off, 0
 
 
 def _collect(p) -> Prepared:
@@ -51,6 +54,11 @@ def _collect(p) -> Prepared:
     pl = (C.c_int64 * 6)()
     if lib.hispmv_prep_plan(p, 256, pl) == HISPMV_OK:
         out.plan = dict(zip(("threads", "group_slices", "lds_floats", "ytile_floats", "groups", "lds_bytes"), (int(v) for v in pl)))
+    cnt = (C.c_int64 * 2)()
+    if lib.hispmv_prep_apply_plan(p, 256, cnt) == HISPMV_OK:
+        out.staged_words = arr(lib.hispmv_prep_words(p), n_slices * se)
+        out.groups = arr(lib.hispmv_prep_groups(p), int(cnt[0]) * 4, (-1, 4))
+        out.frags = arr(lib.hispmv_prep_frags(p), int(cnt[1]) * 4, (-1, 4))
     lib.hispmv_prep_free(p)
     return out
 

@@ -152,6 +152,13 @@ const int32_t* hispmv_prep_fix(const hispmv_prep* p);         /* n_split_rows x 
  * floats per wavefront, workgroups, total dynamic LDS bytes per workgroup. */
 int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
 
+/* Applies that plan to the prepared stream IN PLACE (the words of LDS-staged groups then carry window
+ * indices instead of columns) and exposes its tables: groups = n x {frag_begin, frag_count, lds_floats, 0},
+ * frags = m x {col_start, len, lds_off, 0}.  counts[0..1] = n, m. */
+int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[2]);
+const int32_t* hispmv_prep_groups(const hispmv_prep* p);
+const int32_t* hispmv_prep_frags(const hispmv_prep* p);
+
 /* Library identification: "hispmv-amd <version> gfx950". */
 const char* hispmv_version(void);
 

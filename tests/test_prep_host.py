@@ -205,3 +205,33 @@ def test_launch_plans_respect_the_lds_of_a_cu():
         per_slice_rows = np.diff(np.concatenate([P.hdr[:, 0], [rows]]))
         assert pl["ytile_floats"] >= per_slice_rows.max() and pl["ytile_floats"] <= 1024
         assert pl["groups"] * pl["group_slices"] >= P.n_slices
+
+
+def test_fragment_windows_invert_to_the_original_columns():
+    """LDS-staged groups: the device stream carries window indices; through the group's fragment list they
+    map back to exactly the columns of the generic stream, fragments are 64-byte-block aligned runs that do
+    not overlap in the window, and groups that are not staged keep their global columns."""
+    rng = np.random.default_rng(8)
+    rows = 30000
+    off = np.sort(rng.choice(np.arange(-6000, 6000), 12, replace=False))           # stencil-like: 12 diagonals x runs of 3
+    r = np.repeat(np.arange(rows), 36)
+    c = (r + np.repeat(off, 3)[None, :].repeat(rows, 0).reshape(-1) + np.tile(np.arange(3), rows * 12)) % rows
+    P = prep_from_coo(r, c, np.ones(r.size, np.float32), rows, rows)
+    assert P.plan["lds_floats"] > 0 and P.groups[:, 1].max() > 1            # staged, with real multi-fragment windows
+    G = P.plan["group_slices"]
+    gen_col = ((P.words >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(np.int64).reshape(-1, P.slice_elems)
+    dev_col = ((P.staged_words >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(np.int64).reshape(-1, P.slice_elems)
+    assert np.array_equal(P.words & np.uint64(0x80000000FFFFFFFF), P.staged_words & np.uint64(0x80000000FFFFFFFF))
+    for g, (fb, fc, lds, _) in enumerate(P.groups):
+        sl = slice(g * G, min((g + 1) * G, P.n_slices))
+        if fc == 0:
+            assert np.array_equal(gen_col[sl], dev_col[sl])
+            continue
+        fr = P.frags[fb:fb + fc]
+        assert np.all(fr[:, 0] % 16 == 0) and np.all(fr[:, 1] % 16 == 0) and np.all(fr[:, 1] <= 2048)
+        assert np.array_equal(fr[:, 2], np.concatenate([[0], np.cumsum(fr[:, 1])[:-1]])) and fr[:, 1].sum() == lds
+        assert lds <= P.plan["lds_floats"]
+        idx = dev_col[sl].reshape(-1)
+        k = np.searchsorted(fr[:, 2], idx, side="right") - 1                # fragment holding each window index
+        back = fr[k, 0] + (idx - fr[k, 2])
+        assert np.array_equal(back, gen_col[sl].reshape(-1))
