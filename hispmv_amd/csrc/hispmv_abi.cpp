@@ -296,7 +296,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
         return hip_fail(nullptr, e, "hipMalloc(err flag)");
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
-        c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : 2;
+        c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = c.release();
     return HISPMV_OK;
@@ -451,7 +451,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.n_slices = ns; d.n_groups = (ns + p.plan.group_slices - 1) / p.plan.group_slices;
                 d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads; d.lds_floats = p.plan.lds_floats;
                 d.ytile_floats = std::min(kSliceElems, (max_rows + 63) & ~63);
-                if ((size_t)(d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 > 160 * 1024 - 512)
+                if ((size_t)(d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 + (size_t)d.group_slices * 8 > 160 * 1024 - 256)
                     return fail(c, HISPMV_EINVAL, "internal: launch plan exceeds the LDS of a CU");
                 d.n_fix_short = (int32_t)p.fix_short.size(); d.n_fix_long = (int32_t)p.fix_long.size();
                 d.rows = m.rows; d.cols = m.cols;
@@ -462,9 +462,17 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 // ... and every slice must be in flight at once (one slice per wavefront): if a wavefront had a second
                 // slice, a workgroup's first slice would wait for the predecessor's LAST slice, which waits for that
                 // workgroup's first slice, ... -- one serial chain through the whole grid (measured: 14x slower).
+                // ("resident" also asks for one slice per wavefront: with longer per-wave chunks the look-back is correct
+                // -- chains inside the group go through an LDS mailbox, the chain that crosses into the group is
+                // deferred to the end -- but the wavefronts of a workgroup then wait on each other every round and
+                // the big matrices lose more than the 5 us fix-up launch costs: PFlow 77.6 vs 70.8 us)
                 const bool resident = d.n_groups <= (int64_t)c->n_cus * per_cu && d.group_slices <= d.block_threads / 64;
-                d.lookback = c->carry_mode == 1 || (c->carry_mode == 2 && resident);
-                d.use_ticket = !resident;
+                // carry_mode: 0 fix-up launch; 1 look-back for every plan, workgroups in blockIdx order (relies on the
+                // dispatcher starting workgroups in increasing id order -- observed, not contractual; the wait is
+                // bounded and reports instead of hanging); 3 the same with start-order tickets (contract-safe);
+                // 2 (auto) look-back when the whole grid is co-resident, fix-up otherwise
+                d.lookback = c->carry_mode == 1 || c->carry_mode == 3 || (c->carry_mode == 2 && resident);
+                d.use_ticket = c->carry_mode == 3;
             }
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));

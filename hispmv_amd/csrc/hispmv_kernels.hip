@@ -63,6 +63,40 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+// Sum of the carries the `chain_len` slices before `cur` published for this launch (lane k polls granule
+// cur - chain_len + k, k += 64; fixed summation order).  Bounded wait: an expired poll sets *lb.err.
+// Slices of this workgroup (index >= first) are read from the group's LDS mailbox `local` (a neighbour
+// wavefront published them a moment ago: ~100 cycles instead of an L2-bypassing round trip per slice), slices
+// of earlier workgroups from the global granules.
+__device__ __forceinline__ float lookback_chain(const LookbackArgs& lb, const volatile unsigned long long* local,
+                                                long long first, long long cur, int chain_len, int lane) {
+    float part = 0.0f;
+    for (int k = lane; k < chain_len; k += 64) {
+        const long long src = cur - chain_len + k;
+        unsigned long long v;
+        int spins = 0;
+        if (src >= first) {
+            v = local[src - first];
+            while ((unsigned)(v >> 32) != lb.epoch && spins < kLookbackSpinMax) {
+                __builtin_amdgcn_s_sleep(1);
+                v = local[src - first];
+                ++spins;
+            }
+        } else {
+            const unsigned long long* g = lb.gran + src;
+            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((unsigned)(v >> 32) != lb.epoch && spins < kLookbackSpinMax) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++spins;
+            }
+        }
+        if ((unsigned)(v >> 32) != lb.epoch) *lb.err = 1;   // report, never hang
+        part += i2f((int)(unsigned)v);
+    }
+    return wave_sum(part);
+}
+
 // ---------------------------------------------------------------------------
 // Slice kernel.  One workgroup owns a GROUP of consecutive slices (the analogue of a PE group fed by
 // one x window, LoadB base_functions.cpp:105-150); its wavefronts take the group's slices round-robin.
@@ -94,6 +128,9 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     float* const ytile = xs + (USE_LDS ? lds_floats : 0) + wave * ytile_floats;
+    // look-back mailbox of the group: one {carry, launch tag} per slice, published by the wavefront that owns it
+    volatile unsigned long long* const mbox =
+        (volatile unsigned long long*)(xs + (USE_LDS ? lds_floats : 0) + (blockDim.x >> 6) * ytile_floats);
     long long group = blockIdx.x;
     if (LOOKBACK) {
         // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
@@ -127,6 +164,10 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         h = hdr[slice];
     }
 
+    if (LOOKBACK) {
+        for (int i = threadIdx.x; i < group_slices; i += blockDim.x) mbox[i] = 0ull;   // tag 0 = not published
+        if (!USE_LDS) __syncthreads();
+    }
     // LoadB: stage the x fragments of this group (runs of 64-byte blocks its slices touch) into LDS; the
     // words of a staged group already carry the index into this window instead of the column.
     bool in_lds = false;
@@ -151,6 +192,15 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         }
         __syncthreads();
     }
+
+    // Look-back bookkeeping: a chain that reaches back BEFORE this group's first slice is resolved after the
+    // loop (at most one row crosses the group boundary, so at most one slice per workgroup is deferred).  Inside
+    // the group a slice's predecessors are handled in the same or an earlier round; the previous workgroup's last
+    // slice is handled in ITS last round -- waiting for it mid-loop would stall this wavefront for the whole
+    // kernel (and, chained through every workgroup, serialise the grid: measured 14x).
+    long long def_slice = -1;
+    int def_row = 0, def_len = 0;
+    float def_t = 0.0f, def_b = 0.0f;
 
     while (slice < last) {
         int row = __builtin_amdgcn_readfirstlane(h.x);
@@ -230,28 +280,19 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         }
 
         float chain = 0.0f;
+        bool deferred = false;
         if (LOOKBACK) {
             // publish this slice's open partial sum as ONE 8-byte {value, launch tag} granule ...
-            if (lane == 0)
-                __hip_atomic_store(lb.gran + cur, ((unsigned long long)lb.epoch << 32) | (unsigned)f2i(carry_step),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                const unsigned long long granule = ((unsigned long long)lb.epoch << 32) | (unsigned)f2i(carry_step);
+                mbox[cur - first] = granule;
+                __hip_atomic_store(lb.gran + cur, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // ... and collect the parts of the first row that earlier slices hold (rows "shared" between
             // wavefronts): lane k polls the granule of slice (s - chain_len + k); fixed summation order.
-            if (chain_len > 0) {
-                float part = 0.0f;
-                for (int k = lane; k < chain_len; k += 64) {
-                    const unsigned long long* g = lb.gran + (cur - chain_len + k);
-                    unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int spins = 0;
-                    while ((unsigned)(v >> 32) != lb.epoch && spins < kLookbackSpinMax) {
-                        __builtin_amdgcn_s_sleep(2);
-                        v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ++spins;
-                    }
-                    if ((unsigned)(v >> 32) != lb.epoch) *lb.err = 1;   // bounded wait: report, never hang
-                    part += i2f((int)(unsigned)v);
-                }
-                chain = wave_sum(part);
+            deferred = chain_len > (int)(cur - first);     // the chain leaves this group: resolve after the loop
+            if (chain_len > 0 && !deferred) {
+                chain = lookback_chain(lb, mbox, first, cur, chain_len, lane);
 #pragma unroll
                 for (int j = 0; j < kSliceSteps; ++j) {
                     const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
@@ -259,6 +300,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
                     else if (!e0 && e1 && r0[j] == row_first) t1[j] += chain;
                 }
             }
+            if (deferred) { def_slice = cur; def_row = row_first; def_len = chain_len; }
         }
 
         // AccumBuffer -> Compute_C: the row totals go through this wavefront's LDS tile (one ds_write per row
@@ -272,15 +314,27 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         }
         for (int i = lane; i < n_rows; i += 64) {
             const float t = ytile[i];
+            // the first row of a deferred slice is written after the loop, once its chain is known
+            const unsigned dst = (LOOKBACK && deferred && i == 0) ? kNoAccess : (unsigned)(row_first + i) << 2;
             if (HAS_BETA) {
                 const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
                               : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(row_first + i) << 2, 0, 0));
-                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (unsigned)(row_first + i) << 2, 0, 0);
+                if (LOOKBACK && deferred && i == 0) { def_t = t; def_b = b; }
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, dst, 0, 0);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, (unsigned)(row_first + i) << 2, 0, 0);
+                if (LOOKBACK && deferred && i == 0) def_t = t;
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, dst, 0, 0);
             }
         }
         if (!LOOKBACK && lane == 0) carry[cur] = carry_step;
+    }
+    if (LOOKBACK && def_slice >= 0) {     // wave-uniform: the row that crosses into this group from the previous one
+        const float chain = lookback_chain(lb, mbox, first, def_slice, def_len, lane);
+        if (lane == 0) {
+            const float t = def_t + chain;
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * t + beta * def_b : alpha * t), ry,
+                                                  (unsigned)def_row << 2, 0, 0);
+        }
     }
 }
 
@@ -313,7 +367,8 @@ __global__ __launch_bounds__(256) void spmv_fixup_long_kernel(const int4* __rest
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
 static void launch_slices(const SpmvDeviceMatrix& m, const LookbackArgs& lb, const float* x, const float* bias, float* y,
                           float alpha, float beta, hipStream_t stream) {
-    const size_t lds = ((USE_LDS ? (size_t)m.lds_floats : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float);
+    const size_t lds = ((USE_LDS ? (size_t)m.lds_floats : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float) +
+                       (LOOKBACK ? (size_t)m.group_slices * 8 : 0);
     hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS, LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
                        (const uint4*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
                        (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, lb);

@@ -109,7 +109,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         // loads (fragment table, x) in front of it and buys nothing -- x is gathered through L2
         if (n < 512 && !force) break;
         Cfg c = c0;
-        c.cap = std::min(c.cap, ((160 * 1024 - 1024) / c.per_cu - ytile * (c.threads / 64) * 4) / 4);
+        c.cap = std::min(c.cap, ((160 * 1024 - 4096) / c.per_cu - ytile * (c.threads / 64) * 4) / 4);   // 4 KiB: look-back mailbox, static LDS
         c.cap &= ~(kFragBlock - 1);
         if (c.cap < 256) continue;
         int64_t G = c.slices;
