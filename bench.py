@@ -233,6 +233,7 @@ def main():
     fence()
     t_wall = time.perf_counter() - t_start
     t_dev = ev0.elapsed_time(ev1) * 1e-3          # HIP events on the launch stream
+    fpga.synchronize()                            # raises if a bounded in-kernel wait (carry look-back) expired
     if world > 1:
         tt = torch.tensor([t_wall, t_dev], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
