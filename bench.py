@@ -194,9 +194,23 @@ def main():
     n_streams = max(1, args.streams)
     side = [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     lanes = [stream] + side
-    order = sorted(range(len(mats)), key=lambda i: -mats[i]["device_bytes"])
-    for k, i in enumerate(order):
-        mats[i]["lane"] = k % n_streams
+    # longest-processing-time-first: one untimed pass measures each launch alone, then every matrix goes to the
+    # stream with the least work so far
+    cost = {}
+    for i, m in enumerate(mats):
+        fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
+        a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_ev.record(stream)
+        fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
+        b_ev.record(stream)
+        torch.cuda.synchronize()
+        cost[i] = a_ev.elapsed_time(b_ev)
+    order = sorted(range(len(mats)), key=lambda i: -cost[i])
+    load = [0.0] * n_streams
+    for i in order:
+        k = min(range(n_streams), key=lambda q: load[q])
+        mats[i]["lane"] = k
+        load[k] += cost[i]
 
     def step():
         if n_streams > 1:

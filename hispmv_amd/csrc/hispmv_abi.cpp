@@ -362,6 +362,7 @@ HISPMV_API int hispmv_create_sparse_handle_from_csr(hispmv_ctx* c, const int32_t
     if (!c) return HISPMV_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     if (rows <= 0 || cols <= 0 || !rp) return fail(c, HISPMV_EINVAL, "bad CSR arguments");
+    if (rows >= (1 << 30) || cols >= (1 << 30)) return fail(c, HISPMV_EINVAL, "dimension >= 2^30 is not supported");
     try {
         auto t0 = std::chrono::steady_clock::now();
         Csr csr;
