@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void lab_kernel(const uint4* __restrict__ wor
                 x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w[j].w & ~kRowEndBit) << 2, 0, 0));
             }
         }
-        if (OUT) {
+        if (OUT == 1) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
                 const bool e0 = (w[j].y & kRowEndBit) != 0, e1 = (w[j].w & kRowEndBit) != 0;
@@ -151,7 +151,22 @@ __global__ __launch_bounds__(1024) void lab_kernel(const uint4* __restrict__ wor
                 }
             }
         }
-        if (OUT) {
+        if (OUT == 2) {
+            float* yt = xs + (LDS ? x_span : 0) + wave * 1024;
+            const int row_first = __builtin_amdgcn_readfirstlane(h.x);
+            const int n_rows = row - row_first;
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
+                if (e0) yt[r0[j] - row_first] = t0[j];
+                if (e1) yt[r0[j] - row_first + (e0 ? 1 : 0)] = t1[j];
+            }
+            for (int i = lane; i < n_rows; i += 64) {
+                const float t = yt[i];
+                const float b = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(row_first + i) << 2, 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (unsigned)(row_first + i) << 2, 0, 0);
+            }
+        } else if (OUT) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
                 const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
@@ -205,9 +220,9 @@ template <int SCAN, int OUT, bool LDS, bool PIPE, bool NT = false>
 static float run(const Mat& m, int threads, int per_cu, int reps, int group_override = 0) {
     const int group = group_override ? group_override : (int)((m.n_slices + 256LL * per_cu - 1) / (256LL * per_cu));
     const unsigned grid = (unsigned)((m.n_slices + group - 1) / group);
-    const size_t lds = LDS ? (size_t)m.x_span * 4 : 0;
+    const size_t lds = (LDS ? (size_t)m.x_span * 4 : 0) + (OUT == 2 ? (size_t)(threads / 64) * 4096 : 0);
     auto k = lab_kernel<SCAN, OUT, LDS, PIPE, NT>;
-    if (LDS) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, 0, (const uint4*)m.words, m.hdr, m.x, m.bias, m.y, m.carry, 0.5f, -2.f, m.n_slices, group, m.x_base, m.x_span, m.cols, m.rows);
     CK(hipDeviceSynchronize());
@@ -241,6 +256,32 @@ static Mat make_stencil(int rows, int row_len, int band, int run, unsigned seed)
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'E') {   // current product structure (LDS row-total tile) and its parts
+        Mat B = make(250000, 4096 * 4, 200, 8000, 4, 2);
+        Mat C = make(6000000, 16384, 8, 8000, 2, 3);
+        Mat D = make_stencil(1000000, 50, 30000, 4, 5);
+        struct { const char* name; Mat* m; bool lds; } mm[] = {{"B long rows, x in LDS", &B, true}, {"C short rows, x in LDS", &C, true}, {"D stencil, global gather", &D, false}};
+        for (auto& q : mm) {
+            const Mat& m = *q.m;
+            printf("== %s: slices %lld, alg %.0f MB\n", q.name, m.n_slices, m.alg_bytes / 1e6);
+            for (int round = 0; round < 2; ++round) {
+                auto rep = [&](const char* v, float ms) { printf("  r%d %-44s %8.1f us  %7.1f GB/s\n", round, v, ms * 1e3, m.alg_bytes / ms / 1e6); fflush(stdout); };
+                if (q.lds) {
+                    rep("lds scan1 ytile  512t x2/CU", run<1, 2, true, true>(m, 512, 2, 5));
+                    rep("lds scan1 out0   512t x2/CU", run<1, 0, true, true>(m, 512, 2, 5));
+                    rep("lds scan1 ytile 1024t x1/CU", run<1, 2, true, true>(m, 1024, 1, 5));
+                    rep("lds scan1 ytile  256t x4/CU", run<1, 2, true, true>(m, 256, 4, 5));
+                    rep("lds scan1 ytile nopipe 512t x2/CU", run<1, 2, true, false>(m, 512, 2, 5));
+                } else {
+                    rep("glb scan1 ytile  256t 8 slices/WG", run<1, 2, false, true>(m, 256, 4, 5, 8));
+                    rep("glb scan1 out0   256t 8 slices/WG", run<1, 0, false, true>(m, 256, 4, 5, 8));
+                    rep("glb scan1 ytile  512t 16 slices/WG", run<1, 2, false, true>(m, 512, 2, 5, 16));
+                    rep("glb scan1 ytile nopipe 256t 8 slices/WG", run<1, 2, false, false>(m, 256, 4, 5, 8));
+                }
+            }
+        }
+        return 0;
+    }
     if (argc > 1) {   // second experiment: stencil-like (PFlow-like) matrix, L2 gathers with reuse between rows
         Mat D = make_stencil(1000000, 50, 30000, 4, 5);
         printf("== D stencil 50/row band 30000 run 4: slices %lld, alg %.0f MB\n", D.n_slices, D.alg_bytes / 1e6);
