@@ -216,6 +216,7 @@ static Mat make(int rows, int cols, int row_len, int band, int run, unsigned see
     return d;
 }
 
+static void* g_flush = nullptr;   // when set: 1 GiB memset between warm-up and the timed launches (cold caches)
 template <int SCAN, int OUT, bool LDS, bool PIPE, bool NT = false>
 static float run(const Mat& m, int threads, int per_cu, int reps, int group_override = 0) {
     const int group = group_override ? group_override : (int)((m.n_slices + 256LL * per_cu - 1) / (256LL * per_cu));
@@ -225,6 +226,7 @@ static float run(const Mat& m, int threads, int per_cu, int reps, int group_over
     if (lds) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, 0, (const uint4*)m.words, m.hdr, m.x, m.bias, m.y, m.carry, 0.5f, -2.f, m.n_slices, group, m.x_base, m.x_span, m.cols, m.rows);
+    if (g_flush) CK(hipMemsetAsync(g_flush, 1, 1u << 30, 0));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i)
@@ -256,6 +258,34 @@ static Mat make_stencil(int rows, int row_len, int band, int run, unsigned seed)
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'S') {   // small short-row matrices: where do 20 us go?
+        Mat A = make(682862, 682862, 4, 682862, 1, 7);      // ASIC_680k-like: uniform columns
+        Mat A2 = make(682862, 682862, 4, 64, 1, 7);         // same shape, columns next to the diagonal
+        Mat N = make(414604, 414604, 6, 50000, 1, 8);       // nxp1-like
+        Mat L = make(20000, 20000, 128, 3000, 4, 9);        // same stream size as A, long rows
+        float* flush; CK(hipMalloc(&flush, 1u << 30));
+        struct { const char* name; Mat* m; } mm[] = {{"A uniform 4/row", &A}, {"A2 diagonal 4/row", &A2}, {"N banded 6/row", &N}, {"L long rows", &L}};
+        for (auto& q : mm) {
+            const Mat& m = *q.m;
+            printf("== %s: slices %lld, alg %.1f MB\n", q.name, m.n_slices, m.alg_bytes / 1e6);
+            for (int round = 0; round < 2; ++round) {
+                auto rep = [&](const char* v, float ms) { printf("  r%d %-44s %8.1f us  %7.1f GB/s\n", round, v, ms * 1e3, m.alg_bytes / ms / 1e6); fflush(stdout); };
+                rep("glb ytile 256t 4 sl/WG", run<1, 2, false, true, true>(m, 256, 4, 20, 4));
+                rep("glb out0  256t 4 sl/WG", run<1, 0, false, true, true>(m, 256, 4, 20, 4));
+                rep("glb out1  256t 4 sl/WG", run<1, 1, false, true, true>(m, 256, 4, 20, 4));
+                rep("glb noscan out0 256t 4 sl/WG", run<0, 0, false, true, true>(m, 256, 4, 20, 4));
+                rep("glb ytile 256t 8 sl/WG", run<1, 2, false, true, true>(m, 256, 4, 20, 8));
+                rep("glb ytile 512t 16 sl/WG", run<1, 2, false, true, true>(m, 512, 2, 20, 16));
+                rep("glb ytile 256t 2 sl/WG", run<1, 2, false, true, true>(m, 256, 4, 20, 2));
+                rep("glb ytile 128t 2 sl/WG", run<1, 2, false, true, true>(m, 128, 4, 20, 2));
+                g_flush = flush;
+                rep("glb ytile 256t 4 sl/WG, 1 rep after flush", run<1, 2, false, true, true>(m, 256, 4, 1, 4));
+                rep("glb out0  256t 4 sl/WG, 1 rep after flush", run<1, 0, false, true, true>(m, 256, 4, 1, 4));
+                g_flush = nullptr;
+            }
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'E') {   // current product structure (LDS row-total tile) and its parts
         Mat B = make(250000, 4096 * 4, 200, 8000, 4, 2);
         Mat C = make(6000000, 16384, 8, 8000, 2, 3);
