@@ -188,10 +188,13 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
     //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
     //  * x larger than an XCD's L2: L2-sized tiles.
     int32_t tw = 0;
-    if (m->parts[0].plan.lds_floats == 0) {
+    const LaunchPlan& whole = m->parts[0].plan;
+    // (a window that leaves more than a tenth of the gathers to L2 counts as "does not fit" here)
+    const bool spilling = whole.lds_floats > 0 && whole.global_elems * 10 > m->parts[0].st.n_slices * (int64_t)kSliceElems;
+    if (whole.lds_floats == 0 || spilling) {
         if (csr.cols <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096)
             tw = ((csr.cols + 1) / 2 + 63) & ~63;
-        else tw = column_tile_width(csr.cols, c->col_tile_bytes);
+        else if (whole.lds_floats == 0) tw = column_tile_width(csr.cols, c->col_tile_bytes);
     }
     if (tw > 0) {
         m->col_tile_width = tw;
@@ -204,7 +207,8 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
         // two tiles were meant to bring the x window into LDS: if they still gather through L2, tiling only
         // costs a launch and a read-modify-write of y -- go back to the single stream
         bool lds_goal = csr.cols <= 2 * kMaxLdsFloats, all_lds = true;
-        for (auto& p : m->parts) all_lds = all_lds && p.plan.lds_floats > 0;
+        for (auto& p : m->parts)
+            all_lds = all_lds && p.plan.lds_floats > 0 && p.plan.global_elems * 50 <= p.st.n_slices * (int64_t)kSliceElems;
         if (lds_goal && !all_lds) {
             m->parts.clear();
             m->col_tile_width = 0;
@@ -420,13 +424,14 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 if ((rc = upload(c, m, p.plan.groups.data(), p.plan.groups.size(), &dg)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.plan.frags.data(), p.plan.frags.size(), &dfr)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.st.words.data(), p.st.words.size(), &dw)) != HISPMV_OK) return rc;
-                // device header: {row_base, chain_len, rows ending in the slice, 0} (the column window of a slice is
-                // only needed by the planner)
+                // device header: {row_base, chain_len, rows ending in the slice, 1 if some of its elements lie outside
+                // the group's x window} (the column window of a slice is only needed by the planner)
                 std::vector<SliceHdr>& hh = p.st.hdr;
                 int max_rows = 1;
                 for (int64_t sl = 0; sl < ns; ++sl) {
                     const int nr = (sl + 1 < ns ? hh[sl + 1].row_base : m.rows) - hh[sl].row_base;
-                    hh[sl].x_base = nr; hh[sl].x_span = 0;
+                    hh[sl].x_base = nr;
+                    hh[sl].x_span = (!p.plan.slice_spills.empty() && p.plan.slice_spills[(size_t)sl]) ? 1 : 0;
                     max_rows = std::max(max_rows, nr);
                 }
                 if ((rc = upload(c, m, hh.data(), hh.size(), &dh)) != HISPMV_OK) return rc;

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
         const int chain_len = __builtin_amdgcn_readfirstlane(h.y);   // >0: that row began chain_len slices earlier
 
         const int n_rows = __builtin_amdgcn_readfirstlane(h.z);      // rows that end in this slice
+        const bool spills = USE_LDS && __builtin_amdgcn_readfirstlane(h.w) != 0;   // elements outside the x window
         // Compute_C operand: the slice's rows are consecutive, so bias is read with coalesced loads that leave
         // together with the x gathers (first 128 rows here, the rest in the epilogue loop).
         float bpre0 = 0.0f, bpre1 = 0.0f;
@@ -236,11 +237,27 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
 
         // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather) and, for Compute_C, bias[row]
         float x0[kSliceSteps], x1[kSliceSteps];
-        if (USE_LDS && in_lds) {
+        if (USE_LDS && in_lds && !spills) {
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
                 x0[j] = xs[w[j].y & ~kRowEndBit];
                 x1[j] = xs[w[j].w & ~kRowEndBit];
+            }
+        } else if (USE_LDS && in_lds) {
+            // window of the group's most used blocks: the elements outside it (kGlobalColBit) gather through L2 --
+            // lanes inside the window give the buffer load an out-of-range offset (no access, returns 0)
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
+                x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c0 & kGlobalColBit) ? c0 << 2 : kNoAccess, 0, 0));
+                x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c1 & kGlobalColBit) ? c1 << 2 : kNoAccess, 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
+                const float l0 = xs[(c0 & kGlobalColBit) ? 0u : c0], l1 = xs[(c1 & kGlobalColBit) ? 0u : c1];
+                x0[j] = (c0 & kGlobalColBit) ? x0[j] : l0;
+                x1[j] = (c1 & kGlobalColBit) ? x1[j] : l1;
             }
         } else {
 #pragma unroll

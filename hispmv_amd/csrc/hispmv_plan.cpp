@@ -13,62 +13,86 @@ inline int32_t col_of(uint64_t w) { return (int32_t)((w >> 32) & 0x7fffffffu); }
 
 struct Cfg { int threads, slices, cap, per_cu; };   // slices == 0: one chunk per resident workgroup
 
-// Scratch of one thread: the distinct 64-byte blocks of x touched by a range of slices.
+// Scratch of one thread: how often each 64-byte block of x is touched by a range of slices, and which blocks
+// the group stages in LDS.
 struct BlockSet {
-    std::vector<uint8_t> seen;       // bitmap path: one byte per block of the dense span
+    std::vector<uint32_t> cnt;       // dense path: elements per block of the span
     std::vector<int32_t> table;      // hash path: open addressing, -1 = empty
-    std::vector<int32_t> used;       // hash slots to clear
-    std::vector<int32_t> blocks;     // result of collect(): sorted distinct block ids
+    std::vector<uint32_t> tcnt;      //            elements per slot
+    std::vector<int32_t> used;       //            slots to clear
+    std::vector<std::pair<uint32_t, int32_t>> ranked;   // {elements, block}
+    std::vector<int32_t> blocks;     // result: staged blocks, ascending
+    int64_t global_elems = 0;        // result: elements whose block is not staged
 
-    // Number of distinct blocks touched by slices [s0, s1), or limit + 1 as soon as it exceeds `limit`.
-    // With `keep`, `blocks` holds them sorted (only meaningful when the result is <= limit).
-    int64_t collect(const SliceStream& st, int64_t s0, int64_t s1, int64_t limit, bool keep) {
+    // Chooses the blocks slices [s0, s1) stage when at most `limit` blocks fit: all of them, or -- when up to
+    // kSpill times as many are touched -- the `limit` most used ones (the other elements gather through L2).
+    // Returns the number of staged blocks, or -1 when the group touches too many blocks for a window to pay.
+    static constexpr int kSpill = 4;
+    int64_t collect(const SliceStream& st, int64_t s0, int64_t s1, int64_t limit) {
+        blocks.clear(); global_elems = 0;
         int lo = INT32_MAX, hi = -1;
         for (int64_t s = s0; s < s1; ++s) {
             lo = std::min(lo, st.hdr[s].x_base);
             hi = std::max(hi, st.hdr[s].x_base + st.hdr[s].x_span - 1);
         }
-        if (hi < 0) { blocks.clear(); return 0; }
+        if (hi < 0) return 0;
         const int32_t b_lo = lo / kFragBlock, b_hi = hi / kFragBlock;
         const int64_t span_blocks = (int64_t)b_hi - b_lo + 1;
         const uint64_t* w = st.words.data() + s0 * kSliceElems;
         const int64_t n = (s1 - s0) * kSliceElems;
-        int64_t count = 0;
-        if (span_blocks <= 8 * std::max<int64_t>(limit, 64)) {          // dense enough: bitmap, exact
-            seen.assign((size_t)span_blocks, 0);
-            for (int64_t i = 0; i < n; ++i) {
-                uint8_t& f = seen[(size_t)(col_of(w[i]) / kFragBlock - b_lo)];
-                count += (f == 0);
-                f = 1;
+        const int64_t most = kSpill * std::max<int64_t>(limit, 64);
+        ranked.clear();
+        if (span_blocks <= 8 * most) {          // dense enough: one counter per block of the span
+            cnt.assign((size_t)span_blocks, 0);
+            for (int64_t i = 0; i < n; ++i) cnt[(size_t)(col_of(w[i]) / kFragBlock - b_lo)]++;
+            for (int64_t b = 0; b < span_blocks; ++b)
+                if (cnt[(size_t)b]) ranked.emplace_back(cnt[(size_t)b], (int32_t)(b_lo + b));
+        } else {                                // scattered: hash set, gives up early
+            size_t cap = 1024;
+            while (cap < (size_t)(4 * most)) cap <<= 1;
+            if (table.size() != cap) { table.assign(cap, -1); tcnt.assign(cap, 0); }
+            used.clear();
+            bool over = false;
+            for (int64_t i = 0; i < n && !over; ++i) {
+                const int32_t b = col_of(w[i]) / kFragBlock;
+                size_t h = ((uint32_t)b * 2654435761u) & (cap - 1);
+                while (table[h] != -1 && table[h] != b) h = (h + 1) & (cap - 1);
+                if (table[h] == -1) {
+                    table[h] = b; used.push_back((int32_t)h);
+                    if ((int64_t)used.size() > most) over = true;
+                }
+                tcnt[h]++;
             }
-            if (keep && count <= limit) {
-                blocks.clear();
-                for (int64_t b = 0; b < span_blocks; ++b) if (seen[(size_t)b]) blocks.push_back((int32_t)(b_lo + b));
+            if (!over) for (int32_t h : used) ranked.emplace_back(tcnt[(size_t)h], table[(size_t)h]);
+            for (int32_t h : used) { table[(size_t)h] = -1; tcnt[(size_t)h] = 0; }
+            if (over) return -1;
+        }
+        if ((int64_t)ranked.size() > most) return -1;
+        if ((int64_t)ranked.size() > limit) {   // keep the most used blocks (ties: lower block first)
+            auto better = [](const std::pair<uint32_t, int32_t>& a, const std::pair<uint32_t, int32_t>& b) {
+                return a.first != b.first ? a.first > b.first : a.second < b.second;
+            };
+            std::nth_element(ranked.begin(), ranked.begin() + limit, ranked.end(), better);
+            for (size_t k = (size_t)limit; k < ranked.size(); ++k) global_elems += ranked[k].first;
+            ranked.resize((size_t)limit);
+        }
+        // staging a block costs one L2 request, like gathering one element, plus its place in the window: when
+        // blocks used once or twice make up a good part of the window (the stray couplings of an otherwise banded
+        // group) they stay out; a few of them are not worth sending the group's slices down the two-way gather
+        size_t rare = 0;
+        for (const auto& r : ranked) rare += r.first < 3;
+        if (rare * 4 > ranked.size()) {
+            size_t keep = 0;
+            for (size_t k = 0; k < ranked.size(); ++k) {
+                if (ranked[k].first >= 3) ranked[keep++] = ranked[k];
+                else global_elems += ranked[k].first;
             }
-            return count <= limit ? count : limit + 1;
+            ranked.resize(keep);
         }
-        // scattered: hash set with early exit
-        size_t cap = 1024;
-        while (cap < (size_t)(4 * std::max<int64_t>(limit, 64))) cap <<= 1;
-        if (table.size() != cap) table.assign(cap, -1);
-        used.clear();
-        bool over = false;
-        for (int64_t i = 0; i < n && !over; ++i) {
-            const int32_t b = col_of(w[i]) / kFragBlock;
-            size_t h = ((uint32_t)b * 2654435761u) & (cap - 1);
-            while (table[h] != -1 && table[h] != b) h = (h + 1) & (cap - 1);
-            if (table[h] == -1) {
-                table[h] = b; used.push_back((int32_t)h);
-                if (++count > limit) over = true;
-            }
-        }
-        if (keep && !over) {
-            blocks.clear();
-            for (int32_t h : used) blocks.push_back(table[(size_t)h]);
-            std::sort(blocks.begin(), blocks.end());
-        }
-        for (int32_t h : used) table[(size_t)h] = -1;
-        return over ? limit + 1 : count;
+        if (global_elems * 2 > n) return -1;              // the window would serve less than half of the gathers
+        for (const auto& r : ranked) blocks.push_back(r.second);
+        std::sort(blocks.begin(), blocks.end());
+        return (int64_t)blocks.size();
     }
 };
 
@@ -123,23 +147,26 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         }
         const int64_t ng = (n + G - 1) / G;
         const int64_t limit = c.cap / kFragBlock;
-        int64_t ok = 0, staged_blocks = 0;
-#pragma omp parallel reduction(+ : ok, staged_blocks)
+        int64_t staged_blocks = 0, global_elems = 0;
+#pragma omp parallel reduction(+ : staged_blocks, global_elems)
         {
             BlockSet bs;
 #pragma omp for schedule(dynamic, 16)
             for (int64_t g = 0; g < ng; ++g) {
-                const int64_t k = bs.collect(st, g * G, std::min<int64_t>(n, (g + 1) * G), limit, false);
-                if (k <= limit) { ok++; staged_blocks += k; }
+                const int64_t s0 = g * G, s1 = std::min<int64_t>(n, (g + 1) * G);
+                const int64_t k = bs.collect(st, s0, s1, limit);
+                if (k < 0) global_elems += (s1 - s0) * kSliceElems;
+                else { staged_blocks += k; global_elems += bs.global_elems; }
             }
         }
-        if ((double)ok < 0.9 * (double)ng) continue;
-        // cost: x bytes staged into LDS relative to the stream bytes (L2 -> LDS is ~5x cheaper per byte than the
-        // HBM stream), plus a penalty for fewer than 16 resident wavefronts per CU
+        // cost, with "every element gathers through L2" = 1: L2 requests (one per staged 64-byte block, one per
+        // element outside the window) per element, x bytes staged into LDS relative to the stream bytes (L2 -> LDS
+        // is ~5x cheaper per byte than the HBM stream), and a penalty for fewer than 16 resident wavefronts per CU
         const int waves = c.per_cu * c.threads / 64;
-        const double cost = 0.2 * (double)staged_blocks * kFragBlock * 4.0 / ((double)n * kSliceElems * 8.0) +
+        const double cost = ((double)staged_blocks + (double)global_elems) / ((double)n * kSliceElems) +
+                            0.2 * (double)staged_blocks * kFragBlock * 4.0 / ((double)n * kSliceElems * 8.0) +
                             0.3 * std::max(0, 16 - waves) / 16.0;
-        if (cost < best_cost) { best_cost = cost; have = true; chosen = c; chosen_G = G; }
+        if (cost < best_cost && cost < 0.8) { best_cost = cost; have = true; chosen = c; chosen_G = G; }
     }
     if (!have) {   // scattered columns: plain L2 gathers, small workgroups
         best.block_threads = 256; best.group_slices = (n / 8 < 1024) ? 4 : 8; best.lds_floats = 0; best.per_cu = 4;
@@ -152,6 +179,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
     const int64_t G = chosen_G, ng = (n + G - 1) / G, limit = chosen.cap / kFragBlock;
     best.block_threads = chosen.threads; best.group_slices = (int)G; best.per_cu = chosen.per_cu;
     best.groups.assign((size_t)ng, GroupDesc{0, 0, 0, 0});
+    best.slice_spills.assign((size_t)n, 0);
     std::vector<std::vector<Frag>> gfrags((size_t)ng);
 #pragma omp parallel
     {
@@ -160,8 +188,8 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
 #pragma omp for schedule(dynamic, 16)
         for (int64_t g = 0; g < ng; ++g) {
             const int64_t s0 = g * G, s1 = std::min<int64_t>(n, (g + 1) * G);
-            const int64_t k = bs.collect(st, s0, s1, limit, true);
-            if (k > limit || k == 0) continue;
+            const int64_t k = bs.collect(st, s0, s1, limit);
+            if (k <= 0) continue;
             const std::vector<int32_t>& blocks = bs.blocks;
             // fragments = runs of consecutive blocks, split at kFragMaxLen
             std::vector<Frag>& fr = gfrags[(size_t)g];
@@ -174,15 +202,20 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
                 i = j;
             }
             best.groups[(size_t)g].lds_floats = off;
-            // rewrite the column field of the group's elements: column -> index in the staged window
+            best.groups[(size_t)g].n_global = (int32_t)std::min<int64_t>(bs.global_elems, INT32_MAX);
+            // rewrite the column field of the group's elements: column -> index in the staged window, or the
+            // column itself with kGlobalColBit for the elements whose block is not staged
             uint64_t* w = st.words.data() + s0 * kSliceElems;
             const int64_t ne = (s1 - s0) * kSliceElems;
             for (int64_t i = 0; i < ne; ++i) {
                 const int32_t col = col_of(w[i]);
                 const int32_t b = col / kFragBlock;
-                const int32_t r = (int32_t)(std::lower_bound(blocks.begin(), blocks.end(), b) - blocks.begin());
-                const uint32_t idx = (uint32_t)r * kFragBlock + (uint32_t)(col % kFragBlock);
+                const auto it = std::lower_bound(blocks.begin(), blocks.end(), b);
+                const bool inside = it != blocks.end() && *it == b;
+                const uint32_t idx = inside ? (uint32_t)(it - blocks.begin()) * kFragBlock + (uint32_t)(col % kFragBlock)
+                                            : (kGlobalColBit | (uint32_t)col);
                 w[i] = (w[i] & 0x80000000ffffffffull) | ((uint64_t)idx << 32);
+                if (!inside) best.slice_spills[(size_t)(s0 + i / kSliceElems)] = 1;
             }
         }
     }
@@ -194,6 +227,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         best.frags.insert(best.frags.end(), gfrags[(size_t)g].begin(), gfrags[(size_t)g].end());
         max_lds = std::max(max_lds, d.lds_floats);
         best.staged_floats += d.lds_floats;
+        best.global_elems += d.n_global;
     }
     best.lds_floats = (max_lds + 3) & ~3;
     if (best.lds_floats == 0) best.lds_floats = kFragBlock;   // a plan with a window never reports 0

@@ -2,8 +2,9 @@
 // wavefronts it has, and which FRAGMENTS of x it stages in LDS.  The MI355X analogue of the reference's
 // per-matrix configuration search (automation_tool/src/dse.py:23-95 picks channel counts and window sizes
 // per matrix) and of its x window (LoadB fills a BRAM window per column tile, base_functions.cpp:105-150):
-// here the "window" of a workgroup is the set of 64-byte blocks of x its slices touch, staged as a list of
-// contiguous fragments; the element words of such a group carry the LDS index instead of the column.
+// here the "window" of a workgroup is the set of 64-byte blocks of x its slices touch (the most used ones, if
+// they do not all fit), staged as a list of contiguous fragments; the element words of such a group carry the
+// LDS index instead of the column, or kGlobalColBit | column for the few elements outside the window.
 // Host-only code.
 #pragma once
 #include <cstdint>
@@ -15,13 +16,14 @@ namespace hispmv {
 
 constexpr int kFragBlock = 16;            // floats per x block (64 B: one cache-line sector)
 constexpr int kFragMaxLen = 2048;         // fragments longer than this are split so that wavefronts share the staging
-constexpr int kMaxLdsFloats = 30 * 1024;  // largest x window (120 KiB): leaves room for the row-total tiles
+constexpr int kMaxLdsFloats = 38 * 1024;  // largest x window (152 KiB); the row-total tiles and carry slots come off it
 
 struct GroupDesc {        // 16 B per workgroup
     int32_t frag_begin;   // first fragment of the group in the fragment table
     int32_t frag_count;   // 0: the group gathers x through L2 (its words keep global columns)
     int32_t lds_floats;   // floats of x the group stages
-    int32_t pad;
+    int32_t n_global;     // elements of the group whose block is NOT staged (their words carry kGlobalColBit | column
+                          //   and gather through L2): the window holds the group's most used blocks
 };
 
 struct Frag {             // 16 B
@@ -39,7 +41,9 @@ struct LaunchPlan {
     int per_cu = 4;            // resident workgroups per CU the plan was sized for
     std::vector<GroupDesc> groups;
     std::vector<Frag> frags;
+    std::vector<uint8_t> slice_spills;   // per slice: 1 = some of its elements gather through L2 (empty: none does)
     int64_t staged_floats = 0; // sum over groups (diagnostics)
+    int64_t global_elems = 0;  // elements of staged groups that still gather through L2
 };
 
 // Chooses the plan for `st` on a device with n_cus compute units and REWRITES the column field of the

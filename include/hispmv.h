@@ -153,8 +153,9 @@ const int32_t* hispmv_prep_fix(const hispmv_prep* p);         /* n_split_rows x 
 int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
 
 /* Applies that plan to the prepared stream IN PLACE (the words of LDS-staged groups then carry window
- * indices instead of columns) and exposes its tables: groups = n x {frag_begin, frag_count, lds_floats, 0},
- * frags = m x {col_start, len, lds_off, 0}.  counts[0..1] = n, m. */
+ * indices instead of columns -- or 0x40000000 | column for the elements of the group whose 64-byte block of x
+ * is not in the window) and exposes its tables: groups = n x {frag_begin, frag_count, lds_floats, elements
+ * outside the window}, frags = m x {col_start, len, lds_off, 0}.  counts[0..1] = n, m. */
 int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[2]);
 const int32_t* hispmv_prep_groups(const hispmv_prep* p);
 const int32_t* hispmv_prep_frags(const hispmv_prep* p);

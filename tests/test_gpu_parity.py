@@ -141,6 +141,41 @@ def test_column_tiled_scattered_matrix(fpga):
     assert np.array_equal(y.view(np.uint32), emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA).view(np.uint32))
 
 
+def test_window_of_most_used_blocks_with_l2_spill(pyhispmv_mod, monkeypatch):
+    """x slightly too large for one LDS window (45 000 uniformly used columns; column tiling switched off so that
+    the single-stream plan runs): the group's window holds its most used 64-byte blocks and the remaining elements
+    gather through L2 in the same pass.  Also a banded matrix with a few far-away couplings per row (blocks used
+    once or twice stay out of the window).  Bit-exact against the wavefront model."""
+    monkeypatch.setenv("HISPMV_COL_TILE_BYTES", "0")
+    fpga = pyhispmv_mod.FpgaHandle(*HW)
+    rng = np.random.default_rng(21)
+    cases = []
+    rows, cols = 16000, 45000
+    r = np.repeat(np.arange(rows, dtype=np.int32), 500)
+    cases.append((rows, cols, r, rng.integers(0, cols, r.size).astype(np.int32)))
+    rows, cols = 200000, 200000
+    r = np.repeat(np.arange(rows, dtype=np.int32), 24)
+    c = (r + rng.integers(-300, 300, r.size)) % cols
+    far = rng.random(r.size) < 0.08                                   # 8 % of the couplings go anywhere
+    c = np.where(far, rng.integers(0, cols, r.size), c).astype(np.int32)
+    cases.append((rows, cols, r, c))
+    for rows, cols, r, c in cases:
+        v = rng.random(r.size, dtype=np.float32) - 0.5
+        x = rng.random(cols, dtype=np.float32)
+        b = rng.random(rows, dtype=np.float32)
+        idx = fpga.create_sparse_handle(r, c, v, rows, cols)
+        fpga.load_matrices()
+        info = fpga.matrix_info(idx)
+        assert info["col_tiles"] == 1 and info["lds_bytes"] > 0, info
+        y = np.zeros(rows, np.float32)
+        fpga.select_matrix(idx)
+        fpga.run_kernel(x, b, y, ALPHA, BETA)
+        y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
+        assert bwd_err(y, y64, mag) < TOL
+        assert np.array_equal(y.view(np.uint32), emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA).view(np.uint32))
+    fpga.close()
+
+
 def test_general_test_call_sequence_scaled(fpga):
     """apps/general_test.py:22-113 with the same call order, dense 5000x1000 + 100 k random COO
     (duplicates included), checked with the script's own np.allclose(rtol=1e-3) and the 1e-5 gate."""

@@ -210,7 +210,9 @@ def test_launch_plans_respect_the_lds_of_a_cu():
 def test_fragment_windows_invert_to_the_original_columns():
     """LDS-staged groups: the device stream carries window indices; through the group's fragment list they
     map back to exactly the columns of the generic stream, fragments are 64-byte-block aligned runs that do
-    not overlap in the window, and groups that are not staged keep their global columns."""
+    not overlap in the window, and groups that are not staged keep their global columns.  Second case: a
+    window too small for every block a group touches holds the most used blocks; the other elements keep
+    their column, flagged 0x40000000."""
     rng = np.random.default_rng(8)
     rows = 30000
     off = np.sort(rng.choice(np.arange(-6000, 6000), 12, replace=False))           # stencil-like: 12 diagonals x runs of 3
@@ -218,11 +220,22 @@ def test_fragment_windows_invert_to_the_original_columns():
     c = (r + np.repeat(off, 3)[None, :].repeat(rows, 0).reshape(-1) + np.tile(np.arange(3), rows * 12)) % rows
     P = prep_from_coo(r, c, np.ones(r.size, np.float32), rows, rows)
     assert P.plan["lds_floats"] > 0 and P.groups[:, 1].max() > 1            # staged, with real multi-fragment windows
+    _check_window_inversion(P)
+    # 45000 uniformly used columns: more than a window holds -> most used blocks staged, the rest flagged
+    rows2, cols2 = 16000, 45000
+    r2 = np.repeat(np.arange(rows2), 500)
+    c2 = rng.integers(0, cols2, r2.size)
+    P2 = prep_from_coo(r2, c2, np.ones(r2.size, np.float32), rows2, cols2)
+    assert P2.plan["lds_floats"] > 0 and P2.groups[:, 3].max() > 0
+    _check_window_inversion(P2)
+
+
+def _check_window_inversion(P):
     G = P.plan["group_slices"]
     gen_col = ((P.words >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(np.int64).reshape(-1, P.slice_elems)
     dev_col = ((P.staged_words >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(np.int64).reshape(-1, P.slice_elems)
     assert np.array_equal(P.words & np.uint64(0x80000000FFFFFFFF), P.staged_words & np.uint64(0x80000000FFFFFFFF))
-    for g, (fb, fc, lds, _) in enumerate(P.groups):
+    for g, (fb, fc, lds, _n_out) in enumerate(P.groups):
         sl = slice(g * G, min((g + 1) * G, P.n_slices))
         if fc == 0:
             assert np.array_equal(gen_col[sl], dev_col[sl])
@@ -232,6 +245,9 @@ def test_fragment_windows_invert_to_the_original_columns():
         assert np.array_equal(fr[:, 2], np.concatenate([[0], np.cumsum(fr[:, 1])[:-1]])) and fr[:, 1].sum() == lds
         assert lds <= P.plan["lds_floats"]
         idx = dev_col[sl].reshape(-1)
-        k = np.searchsorted(fr[:, 2], idx, side="right") - 1                # fragment holding each window index
-        back = fr[k, 0] + (idx - fr[k, 2])
+        outside = (idx & 0x40000000) != 0                                   # gathered through L2: column kept
+        assert outside.sum() == P.groups[g, 3]
+        idx_in = np.where(outside, 0, idx)
+        k = np.searchsorted(fr[:, 2], idx_in, side="right") - 1             # fragment holding each window index
+        back = np.where(outside, idx & 0x3FFFFFFF, fr[k, 0] + (idx_in - fr[k, 2]))
         assert np.array_equal(back, gen_col[sl].reshape(-1))
