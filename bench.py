@@ -306,6 +306,7 @@ def main():
                        "matrices": len(mats), "nnz_per_step_per_gpu": int(sum(m["nnz"] for m in mats)),
                        "sources": sorted(set(m["source"].split(":")[0] for m in mats)),
                        "alpha": ALPHA, "beta": BETA, "streams": n_streams, "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
+            "passes_over_set": args.warmup + args.steps + 2,   # + the two untimed passes that size the stream assignment
             "hbm_gbs_algorithmic": round(total_bytes / t_wall / 1e9, 1),
             "hbm_pct_of_peak": round(100 * total_bytes / t_wall / 1e9 / (HBM_PEAK_GBS * world), 2),
             "geomean_gflops_per_matrix": None if geo is None else round(geo, 2),

@@ -299,12 +299,19 @@ int main(int argc, char** argv) {
                 if (q.lds) {
                     rep("lds scan1 ytile  512t x2/CU", run<1, 2, true, true>(m, 512, 2, 5));
                     rep("lds scan1 out0   512t x2/CU", run<1, 0, true, true>(m, 512, 2, 5));
+                    rep("lds scan0 ytile  512t x2/CU nt", run<0, 2, true, true, true>(m, 512, 2, 5));
+                    rep("lds scan1 ytile  512t x2/CU nt", run<1, 2, true, true, true>(m, 512, 2, 5));
+                    rep("lds scan0 ytile 1024t x1/CU nt", run<0, 2, true, true, true>(m, 1024, 1, 5));
+                    rep("lds scan1 ytile 1024t x1/CU nt", run<1, 2, true, true, true>(m, 1024, 1, 5));
+                    rep("lds scan0 out0  1024t x1/CU nt", run<0, 0, true, true, true>(m, 1024, 1, 5));
                     rep("lds scan1 ytile 1024t x1/CU", run<1, 2, true, true>(m, 1024, 1, 5));
                     rep("lds scan1 ytile  256t x4/CU", run<1, 2, true, true>(m, 256, 4, 5));
                     rep("lds scan1 ytile nopipe 512t x2/CU", run<1, 2, true, false>(m, 512, 2, 5));
                 } else {
                     rep("glb scan1 ytile  256t 8 slices/WG", run<1, 2, false, true>(m, 256, 4, 5, 8));
                     rep("glb scan1 out0   256t 8 slices/WG", run<1, 0, false, true>(m, 256, 4, 5, 8));
+                    rep("glb scan0 ytile  256t 8 slices/WG nt", run<0, 2, false, true, true>(m, 256, 4, 5, 8));
+                    rep("glb scan1 ytile  256t 8 slices/WG nt", run<1, 2, false, true, true>(m, 256, 4, 5, 8));
                     rep("glb scan1 ytile  512t 16 slices/WG", run<1, 2, false, true>(m, 512, 2, 5, 16));
                     rep("glb scan1 ytile nopipe 256t 8 slices/WG", run<1, 2, false, false>(m, 256, 4, 5, 8));
                 }

@@ -66,7 +66,15 @@ if fetch or write:
         traffic[n[:60]] = {"launches": fetch[1].get(n, 0) if fetch else 0, "read_bytes_per_launch": fk * 1024 * 2, "write_bytes_per_launch": wk * 1024}
         out.append(f"| `{n[:60]}` | {fetch[1].get(n, 0) if fetch else 0} | {fk:.0f} | {fk*1024*2/1e6:.2f} | {wk*1024/1e6:.2f} |")
     out.append("")
-PASSES = 6    # tools/profile_round.sh: --warmup 1 --steps 5, no per-matrix pass
+PASSES = 8    # tools/profile_round.sh: --warmup 1 --steps 5 + bench.py's two untimed passes (stream assignment), no per-matrix pass
+for log in ("fetch.log", "write.log", "trace.log"):     # bench.py states how often it went over the set
+    try:
+        for line in (src / log).read_text().splitlines():
+            if line.startswith("{") and "passes_over_set" in line:
+                PASSES = int(json.loads(line)["passes_over_set"])
+        break
+    except Exception:
+        pass
 tot_r = sum(v["read_bytes_per_launch"] * v["launches"] for v in traffic.values())
 tot_w = sum(v["write_bytes_per_launch"] * v["launches"] for v in traffic.values())
 summary = {"passes": PASSES, "hbm_read_bytes_per_step": tot_r / PASSES, "hbm_write_bytes_per_step": tot_w / PASSES,
