@@ -259,6 +259,40 @@ int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bia
     return HISPMV_OK;
 }
 
+// `vecs` vectors with a shared bias (FpgaHandle::linear): the reference relaunches its kernel per vector
+// (fpga_handle.cpp:366-379); here up to 8 (dense) / 4 (sparse) vectors share one pass over the matrix when the plan allows.
+int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d_x, const float* d_bias, float* d_y,
+                          float alpha, float beta, hipStream_t s) {
+    if (vecs == 1) return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, s);
+    if (m.dense) {
+        hipError_t e = launch_gemv_batched(m.d_dense, m.rows, m.cols, vecs, d_x, d_bias, d_y, alpha, beta, s);
+        if (e != hipSuccess) return hip_fail(c, e, "launch_gemv_batched");
+        return HISPMV_OK;
+    }
+    int64_t k = 0;
+    while (k < vecs) {
+        int nv = kMaxBatch;
+        for (auto& p : m.parts) nv = std::min(nv, spmv_batch_width(p.dev, vecs - k, beta));
+        const float* xk = d_x + k * m.cols;
+        float* yk = d_y + k * m.rows;
+        if (nv < 2) {
+            int rc = launch_matrix(c, m, xk, d_bias, yk, alpha, beta, s);
+            if (rc != HISPMV_OK) return rc;
+            k += 1;
+            continue;
+        }
+        for (size_t t = 0; t < m.parts.size(); ++t) {
+            // column tile t > 0 accumulates on what the earlier tiles wrote: beta = 1, bias = each vector's own y
+            hipError_t e = (t == 0) ? launch_spmv_batched(m.parts[t].dev, nv, xk, d_bias, 0, yk, alpha, beta, s)
+                                    : launch_spmv_batched(m.parts[t].dev, nv, xk, yk, m.rows, yk, alpha, 1.0f, s);
+            if (e != hipSuccess) return hip_fail(c, e, "launch_spmv_batched");
+        }
+        k += nv;
+    }
+    return HISPMV_OK;
+}
+
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -440,9 +474,9 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 // carry per slice; {carry, launch tag} granules and the group ticket of the look-back variant
                 void *carry = nullptr, *gran = nullptr, *ticket = nullptr;
                 const size_t n1 = (size_t)std::max<int64_t>(ns, 1);
-                HIP_TRY(c, hipMalloc(&carry, n1 * sizeof(float)));
+                HIP_TRY(c, hipMalloc(&carry, n1 * kMaxBatch * sizeof(float)));      // one set per vector of a batched pass
                 m.allocs.push_back(carry);
-                HIP_TRY(c, hipMemsetAsync(carry, 0, n1 * sizeof(float), c->stream));
+                HIP_TRY(c, hipMemsetAsync(carry, 0, n1 * kMaxBatch * sizeof(float), c->stream));
                 HIP_TRY(c, hipMalloc(&gran, n1 * sizeof(unsigned long long)));
                 m.allocs.push_back(gran);
                 HIP_TRY(c, hipMemsetAsync(gran, 0, n1 * sizeof(unsigned long long), c->stream));
@@ -509,8 +543,7 @@ static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t nu
     if (beta != 0.0f)
         HIP_TRY(c, hipMemcpyAsync(c->d_bias, bias, (size_t)m.rows * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (int64_t k = 0; k < num_vecs; ++k)
-        if ((rc = launch_matrix(c, m, c->d_x + k * m.cols, c->d_bias, c->d_y + k * m.rows, alpha, beta, c->stream)) != HISPMV_OK) return rc;
+    if ((rc = launch_matrix_vectors(c, m, num_vecs, c->d_x, c->d_bias, c->d_y, alpha, beta, c->stream)) != HISPMV_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipMemcpyAsync(y, c->d_y, (size_t)m.rows * num_vecs * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -42,6 +42,7 @@ struct LookbackArgs {
 };
 
 constexpr int kFixShortMax = 32;
+constexpr int kMaxBatch = 4;                // vectors one pass of the batched slice kernel takes (carry holds kMaxBatch * n_slices)
 
 // Once per process/device before the first launch (raises the dynamic-LDS limit of the slice kernels).
 hipError_t prepare_spmv_kernels();
@@ -51,8 +52,18 @@ hipError_t prepare_spmv_kernels();
 hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, float* y,
                        float alpha, float beta, hipStream_t stream);
 
+// Batched SpMV (linear with several vectors): how many vectors (4, 2 or 1 = use launch_spmv) one pass can take for
+// this matrix, and the launch: vector v is x + v*cols -> y + v*rows; bias_stride 0 (shared) or rows (per vector).
+// Fix-up carry variant whatever m.lookback says: per vector bitwise equal to launch_spmv with lookback = false.
+int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs, float beta);
+hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, const float* bias, int bias_stride, float* y,
+                               float alpha, float beta, hipStream_t stream);
+
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
                        float* y, float alpha, float beta, hipStream_t stream);
+// `vecs` vectors (x + v*cols -> y + v*rows, shared bias), 8/4/2/1 per pass over W; per vector bitwise equal to launch_gemv.
+hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64_t vecs, const float* x, const float* bias,
+                               float* y, float alpha, float beta, hipStream_t stream);
 
 }  // namespace hispmv

@@ -364,13 +364,178 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Batched slice kernel: NV input vectors per pass over the stream (FpgaHandle::linear with num_vecs > 1; the
+// reference runs its kernel once per vector, fpga_handle.cpp:366-379 -- A is read num_vecs times).  Vector v
+// is x + v*cols, its result y + v*rows, its carries carry + v*n_slices; bias is shared (bias_stride 0) or per
+// vector (bias_stride = rows: column tiles t > 0 accumulate on y).  The slice's words stay in registers while
+// the NV vectors go through gather, product, scan and output one after the other, so every vector sees exactly
+// the arithmetic of the single-vector kernel with the fix-up carry variant (bitwise the same y); the next
+// slice is requested after the last vector's products.  The x windows of the NV vectors sit side by side in LDS.
+// Host guarantees: cols % 4 == 0 when USE_LDS, cols*NV < 2^30, rows*NV < 2^30, NV*lds_floats + tiles fit LDS.
+// ---------------------------------------------------------------------------
+template <bool USE_LDS, int NV>
+__global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
+    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const int4* __restrict__ frags,
+    const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
+    float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
+    int lds_floats, int ytile_floats, int cols, int rows, int bias_stride) {
+    extern __shared__ float xs[];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, cols * NV * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, (bias_stride ? rows * NV : rows) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, rows * NV * 4, 0x00020000);
+    constexpr unsigned kNoAccess = 0xffffffffu;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    float* const ytile = xs + (USE_LDS ? NV * lds_floats : 0) + wave * ytile_floats;
+    const long long group = blockIdx.x;
+    const long long first = group * group_slices;
+    const long long last = (first + group_slices < n_slices) ? first + group_slices : n_slices;   // exclusive
+
+    long long slice = first + wave;
+    uint4 w[kSliceSteps];
+    int4 h = int4{0, 0, 0, 0};
+    if (slice < last) {
+        const uint4* p = words + slice * (kSliceElems / 2) + lane;
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) w[j] = load_words(p + j * 64);
+        h = hdr[slice];
+    }
+    bool in_lds = false;
+    if (USE_LDS) {
+        const int4 g = groups[group];
+        in_lds = g.y > 0;
+        for (int v = 0; v < NV; ++v) {
+            const float* xv = x + (size_t)v * cols;
+            for (int f = wave; f < g.y; f += n_waves) {
+                const int4 fr = frags[g.x + f];
+                const float4* src = (const float4*)(xv + fr.x);
+                float4* dst = (float4*)(xs + v * lds_floats + fr.z);
+                for (int i = lane; i < (fr.y >> 2); i += 64) {
+                    if (fr.x + 4 * i + 3 < cols) dst[i] = src[i];
+                    else {
+                        float4 q = float4{0.f, 0.f, 0.f, 0.f};
+                        if (fr.x + 4 * i + 0 < cols) q.x = xv[fr.x + 4 * i + 0];
+                        if (fr.x + 4 * i + 1 < cols) q.y = xv[fr.x + 4 * i + 1];
+                        if (fr.x + 4 * i + 2 < cols) q.z = xv[fr.x + 4 * i + 2];
+                        dst[i] = q;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    while (slice < last) {
+        int row = __builtin_amdgcn_readfirstlane(h.x);
+        const int row_first = row;
+        const int n_rows = __builtin_amdgcn_readfirstlane(h.z);
+        const bool spills = USE_LDS && __builtin_amdgcn_readfirstlane(h.w) != 0;
+        int r0[kSliceSteps];
+        unsigned ends = 0;
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64((w[j].y & kRowEndBit) != 0);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64((w[j].w & kRowEndBit) != 0);
+            r0[j] = row + lanes_below(m0) + lanes_below(m1);
+            row += __builtin_popcountll(m0) + __builtin_popcountll(m1);
+            ends |= ((w[j].y >> 31) << (2 * j)) | ((w[j].w >> 31) << (2 * j + 1));
+        }
+        const long long cur = slice;
+
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const unsigned xoff = (unsigned)v * (unsigned)cols, yoff = (unsigned)v * (unsigned)rows;
+            const unsigned boff = (unsigned)v * (unsigned)bias_stride;
+            const float bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (boff + row_first + lane) << 2 : kNoAccess, 0, 0));
+            const float bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (boff + row_first + lane + 64) << 2 : kNoAccess, 0, 0));
+            float x0[kSliceSteps], x1[kSliceSteps];
+            const float* xw = xs + v * lds_floats;
+            if (USE_LDS && in_lds && !spills) {
+#pragma unroll
+                for (int j = 0; j < kSliceSteps; ++j) {
+                    x0[j] = xw[w[j].y & ~kRowEndBit];
+                    x1[j] = xw[w[j].w & ~kRowEndBit];
+                }
+            } else if (USE_LDS && in_lds) {
+#pragma unroll
+                for (int j = 0; j < kSliceSteps; ++j) {
+                    const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
+                    x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c0 & kGlobalColBit) ? ((c0 & ~kGlobalColBit) + xoff) << 2 : kNoAccess, 0, 0));
+                    x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c1 & kGlobalColBit) ? ((c1 & ~kGlobalColBit) + xoff) << 2 : kNoAccess, 0, 0));
+                }
+#pragma unroll
+                for (int j = 0; j < kSliceSteps; ++j) {
+                    const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
+                    const float l0 = xw[(c0 & kGlobalColBit) ? 0u : c0], l1 = xw[(c1 & kGlobalColBit) ? 0u : c1];
+                    x0[j] = (c0 & kGlobalColBit) ? x0[j] : l0;
+                    x1[j] = (c1 & kGlobalColBit) ? x1[j] : l1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kSliceSteps; ++j) {
+                    x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, ((w[j].y & ~kRowEndBit) + xoff) << 2, 0, 0));
+                    x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, ((w[j].w & ~kRowEndBit) + xoff) << 2, 0, 0));
+                }
+            }
+            float p0[kSliceSteps], p1[kSliceSteps];
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                p0[j] = i2f((int)w[j].x) * x0[j];
+                p1[j] = i2f((int)w[j].z) * x1[j];
+            }
+            if (v == NV - 1) {          // the words are no longer needed: request this wavefront's next slice
+                slice += n_waves;
+                if (slice < last) {
+                    const uint4* p = words + slice * (kSliceElems / 2) + lane;
+#pragma unroll
+                    for (int j = 0; j < kSliceSteps; ++j) w[j] = load_words(p + j * 64);
+                    h = hdr[slice];
+                }
+            }
+            float t0[kSliceSteps], t1[kSliceSteps];
+            float carry_step = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                const bool e0 = (ends >> (2 * j)) & 1u;
+                const bool e1 = (ends >> (2 * j + 1)) & 1u;
+                float q = e1 ? 0.0f : (e0 ? p1[j] : p0[j] + p1[j]);
+                int F = (e0 | e1) ? 1 : 0;
+                seg_scan_wave(q, F);
+                q = F ? q : q + carry_step;
+                const float cin = i2f(__builtin_amdgcn_update_dpp(f2i(carry_step), f2i(q), 0x138, 0xf, 0xf, false));  // wave_shr:1
+                carry_step = i2f(__builtin_amdgcn_readlane(f2i(q), 63));
+                t0[j] = cin + p0[j];
+                t1[j] = e0 ? p1[j] : cin + (p0[j] + p1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
+                if (e0) ytile[r0[j] - row_first] = t0[j];
+                if (e1) ytile[r0[j] - row_first + (e0 ? 1 : 0)] = t1[j];
+            }
+            for (int i = lane; i < n_rows; i += 64) {
+                const float t = ytile[i];
+                const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
+                              : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (boff + row_first + i) << 2, 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (yoff + row_first + i) << 2, 0, 0);
+            }
+            if (lane == 0) carry[(long long)v * n_slices + cur] = carry_step;
+        }
+    }
+}
+
 // Fix-up for rows shared between slices: y[row] += alpha * (carry[first] + ... + carry[first+len-1]),
 // summed in slice order.  One thread per entry (short chains) ...
 __global__ __launch_bounds__(256) void spmv_fixup_short_kernel(const int4* __restrict__ fix, int n,
                                                                const float* __restrict__ carry,
-                                                               float* __restrict__ y, float alpha) {
+                                                               float* __restrict__ y, float alpha,
+                                                               long long carry_stride, long long y_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    carry += blockIdx.y * carry_stride;     // blockIdx.y = vector of a batched pass (0 otherwise)
+    y += blockIdx.y * y_stride;
     const int4 f = fix[i];
     float s = 0.0f;
     for (int k = 0; k < f.z; ++k) s += carry[f.y + k];
@@ -379,10 +544,13 @@ __global__ __launch_bounds__(256) void spmv_fixup_short_kernel(const int4* __res
 // ... or one wavefront per entry (a heavy row spanning many slices).
 __global__ __launch_bounds__(256) void spmv_fixup_long_kernel(const int4* __restrict__ fix, int n,
                                                               const float* __restrict__ carry,
-                                                              float* __restrict__ y, float alpha) {
+                                                              float* __restrict__ y, float alpha,
+                                                              long long carry_stride, long long y_stride) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
+    carry += blockIdx.y * carry_stride;
+    y += blockIdx.y * y_stride;
     const int4 f = fix[i];
     float s = 0.0f;
     for (int k = lane; k < f.z; k += 64) s += carry[f.y + k];
@@ -442,10 +610,61 @@ hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, f
     }
     if (m.n_fix_short > 0)
         hipLaunchKernelGGL(spmv_fixup_short_kernel, dim3((m.n_fix_short + 255) / 256), dim3(256), 0, stream,
-                           m.fix_short, m.n_fix_short, m.carry, y, alpha);
+                           m.fix_short, m.n_fix_short, m.carry, y, alpha, 0LL, 0LL);
     if (m.n_fix_long > 0)
         hipLaunchKernelGGL(spmv_fixup_long_kernel, dim3((m.n_fix_long + 3) / 4), dim3(256), 0, stream,
-                           m.fix_long, m.n_fix_long, m.carry, y, alpha);
+                           m.fix_long, m.n_fix_long, m.carry, y, alpha, 0LL, 0LL);
+    return hipGetLastError();
+}
+
+template <bool USE_LDS, int NV>
+static hipError_t launch_batched(const SpmvDeviceMatrix& m, const float* x, const float* bias, int bias_stride, float* y,
+                                 float alpha, float beta, hipStream_t stream) {
+    const size_t lds = ((USE_LDS ? (size_t)m.lds_floats * NV : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float);
+    static bool raised = false;      // per instantiation
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)spmv_slices_batched_kernel<USE_LDS, NV>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((spmv_slices_batched_kernel<USE_LDS, NV>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
+                       (const uint4*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
+                       (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, bias_stride);
+    return hipGetLastError();
+}
+
+int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs, float beta) {
+    if (beta == 0.0f || vecs < 2) return 1;           // (linear always has beta = 1)
+    if (m.lds_floats > 0 && (m.cols & 3)) return 1;   // the windows of vectors 1.. would be staged from unaligned rows of x
+    for (int nv = kMaxBatch; nv >= 2; nv >>= 1) {
+        if (nv > vecs) continue;
+        if ((int64_t)m.cols * nv >= (1 << 30) || (int64_t)m.rows * nv >= (1 << 30)) continue;
+        const size_t lds = ((size_t)m.lds_floats * nv + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float);
+        if (lds <= 160 * 1024 - 256) return nv;
+    }
+    return 1;
+}
+
+hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, const float* bias, int bias_stride, float* y,
+                               float alpha, float beta, hipStream_t stream) {
+    if (nv != 2 && nv != 4) return hipErrorInvalidValue;
+    if (m.n_slices > 0) {
+        if (m.n_groups <= 0 || m.n_groups > 0x7fffffffLL) return hipErrorInvalidValue;
+        const bool lds = m.lds_floats > 0;
+        hipError_t e;
+        if (nv == 4) e = lds ? launch_batched<true, 4>(m, x, bias, bias_stride, y, alpha, beta, stream)
+                             : launch_batched<false, 4>(m, x, bias, bias_stride, y, alpha, beta, stream);
+        else         e = lds ? launch_batched<true, 2>(m, x, bias, bias_stride, y, alpha, beta, stream)
+                             : launch_batched<false, 2>(m, x, bias, bias_stride, y, alpha, beta, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (m.n_fix_short > 0)     // one fix-up launch for all vectors of the pass (grid.y = vector)
+        hipLaunchKernelGGL(spmv_fixup_short_kernel, dim3((m.n_fix_short + 255) / 256, nv), dim3(256), 0, stream,
+                           m.fix_short, m.n_fix_short, m.carry, y, alpha, (long long)m.n_slices, (long long)m.rows);
+    if (m.n_fix_long > 0)
+        hipLaunchKernelGGL(spmv_fixup_long_kernel, dim3((m.n_fix_long + 3) / 4, nv), dim3(256), 0, stream,
+                           m.fix_long, m.n_fix_long, m.carry, y, alpha, (long long)m.n_slices, (long long)m.rows);
     return hipGetLastError();
 }
 
@@ -454,63 +673,98 @@ hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, f
 // spmv-helper.cpp:717-750).  No packing here: W stays row-major; one workgroup of 4 waves
 // per group of R rows, 16 B per lane loads of W and x, DPP wave reduction, LDS across waves.
 // ---------------------------------------------------------------------------
-template <int R, bool HAS_BETA>
+// NV input vectors per pass over W (linear with num_vecs > 1): vector v is x + v*cols, its result y + v*rows; every
+// (row, vector) pair accumulates in exactly the order of the single-vector kernel, so the results are bitwise the same.
+template <int R, bool HAS_BETA, int NV>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int rows, int cols, float alpha, float beta) {
-    __shared__ float part[4][R];
+    __shared__ float part[4][R][NV];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row0 = blockIdx.x * R;
-    float acc[R];
+    float acc[R][NV];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[r][v] = 0.0f;
 
     if ((cols & 3) == 0) {
         const int n4 = cols >> 2;
         const float4* x4 = (const float4*)x;
         for (int c = threadIdx.x; c < n4; c += 256) {
-            const float4 xv = x4[c];
+            float4 xv[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xv[v] = x4[(size_t)v * n4 + c];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = min(row0 + r, rows - 1);
                 const float4 a = ((const float4*)(W + (size_t)row * cols))[c];
-                acc[r] += a.x * xv.x + a.y * xv.y + a.z * xv.z + a.w * xv.w;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[r][v] += a.x * xv[v].x + a.y * xv[v].y + a.z * xv[v].z + a.w * xv[v].w;
             }
         }
     } else {   // rows are not 16-byte aligned: dword path
         for (int c = threadIdx.x; c < cols; c += 256) {
-            const float xv = x[c];
+            float xv[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xv[v] = x[(size_t)v * cols + c];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = min(row0 + r, rows - 1);
-                acc[r] += W[(size_t)row * cols + c] * xv;
+                const float a = W[(size_t)row * cols + c];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[r][v] += a * xv[v];
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float s = wave_sum(acc[r]);
-        if (lane == 0) part[wv][r] = s;
-    }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float s = wave_sum(acc[r][v]);
+            if (lane == 0) part[wv][r][v] = s;
+        }
     __syncthreads();
-    if (threadIdx.x < R) {
-        const int row = row0 + threadIdx.x;
+    if (threadIdx.x < R * NV) {
+        const int r = threadIdx.x / NV, v = threadIdx.x % NV;
+        const int row = row0 + r;
         if (row < rows) {
-            const float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-            y[row] = HAS_BETA ? alpha * s + beta * bias[row] : alpha * s;
+            const float s = (part[0][r][v] + part[1][r][v]) + (part[2][r][v] + part[3][r][v]);
+            y[(size_t)v * rows + row] = HAS_BETA ? alpha * s + beta * bias[row] : alpha * s;
         }
     }
+}
+
+template <int NV>
+static void launch_gemv_nv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
+                           float* y, float alpha, float beta, hipStream_t stream) {
+    constexpr int R = 4;
+    const unsigned blocks = (unsigned)((rows + R - 1) / R);
+    if (beta != 0.0f)
+        hipLaunchKernelGGL((gemv_rows_kernel<R, true, NV>), dim3(blocks), dim3(256), 0, stream, W, x, bias, y, rows, cols, alpha, beta);
+    else
+        hipLaunchKernelGGL((gemv_rows_kernel<R, false, NV>), dim3(blocks), dim3(256), 0, stream, W, x, bias, y, rows, cols, alpha, beta);
 }
 
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
                        float* y, float alpha, float beta, hipStream_t stream) {
     if (rows <= 0) return hipSuccess;
-    constexpr int R = 4;
-    const unsigned blocks = (unsigned)((rows + R - 1) / R);
-    if (beta != 0.0f)
-        hipLaunchKernelGGL((gemv_rows_kernel<R, true>), dim3(blocks), dim3(256), 0, stream, W, x, bias, y, rows, cols, alpha, beta);
-    else
-        hipLaunchKernelGGL((gemv_rows_kernel<R, false>), dim3(blocks), dim3(256), 0, stream, W, x, bias, y, rows, cols, alpha, beta);
+    launch_gemv_nv<1>(W, rows, cols, x, bias, y, alpha, beta, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64_t vecs, const float* x, const float* bias,
+                               float* y, float alpha, float beta, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    int64_t k = 0;
+    while (k < vecs) {      // 8, 4, 2, 1 vectors per pass over W
+        const float* xk = x + (size_t)k * cols;
+        float* yk = y + (size_t)k * rows;
+        if (vecs - k >= 8) { launch_gemv_nv<8>(W, rows, cols, xk, bias, yk, alpha, beta, stream); k += 8; }
+        else if (vecs - k >= 4) { launch_gemv_nv<4>(W, rows, cols, xk, bias, yk, alpha, beta, stream); k += 4; }
+        else if (vecs - k >= 2) { launch_gemv_nv<2>(W, rows, cols, xk, bias, yk, alpha, beta, stream); k += 2; }
+        else { launch_gemv_nv<1>(W, rows, cols, xk, bias, yk, alpha, beta, stream); k += 1; }
+    }
     return hipGetLastError();
 }
 

@@ -27,19 +27,31 @@ def fpga(pyhispmv_mod):
     h.close()
 
 
-def emulate_device(info, r, c, v, rows, cols, x, b, alpha, beta):
-    """The wavefront model applied the way the device runs the handle: one stream per column tile (tile 0
-    with beta*bias, later tiles accumulating in place), carry variant as reported by matrix_info."""
+def prepared_tiles(info, r, c, v, rows, cols):
+    """The slice streams of the handle's column tiles, packed on the host the way the loader packs them."""
     from hispmv_amd.prep import prep_from_coo
     r, c, v = np.asarray(r), np.asarray(c), np.asarray(v, np.float32)
     width = info["col_tile_width"] if info["col_tiles"] > 1 else cols
-    ye = None
+    tiles = []
     for t in range(info["col_tiles"]):
         sel = (c >= t * width) & (c < (t + 1) * width)
-        P = prep_from_coo(r[sel], c[sel], v[sel], rows, cols)
-        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b if t == 0 else ye, alpha, beta if t == 0 else 1.0, rows,
-                             info["carry_lookback"])
+        tiles.append(prep_from_coo(r[sel], c[sel], v[sel], rows, cols))
+    return tiles
+
+
+def emulate_tiles(tiles, x, b, alpha, beta, rows, mode):
+    ye = None
+    for t, P in enumerate(tiles):
+        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b if t == 0 else ye, alpha, beta if t == 0 else 1.0, rows, mode)
     return ye
+
+
+def emulate_device(info, r, c, v, rows, cols, x, b, alpha, beta, carry=None):
+    """The wavefront model applied the way the device runs the handle: one stream per column tile (tile 0
+    with beta*bias, later tiles accumulating in place), carry variant as reported by matrix_info (or `carry`:
+    a batched pass always uses the fix-up variant, 0)."""
+    return emulate_tiles(prepared_tiles(info, r, c, v, rows, cols), x, b, alpha, beta, rows,
+                         info["carry_lookback"] if carry is None else carry)
 
 
 def csr_truth(r, c, v, rows, x, b, alpha, beta):
@@ -245,6 +257,55 @@ def test_model_test_call_sequence_scaled(fpga):
     assert yb.shape == (3 * 1024,)
     for k in range(3):
         assert np.array_equal(yb[k * 1024:(k + 1) * 1024], fpga.linear(idxs[0], xb[k * 512:(k + 1) * 512], bs[0]))
+
+
+def test_batched_linear_shares_one_pass_over_the_matrix(fpga):
+    """linear() with several vectors (fpga_handle.cpp:336-379 runs the kernel once per vector): here 8/4/2 (dense)
+    or 4/2 (sparse) vectors share one pass.  Dense: bitwise equal to the single-vector call.  Sparse: every vector
+    bitwise equal to the wavefront model with the fix-up carry variant -- LDS-window plan, L2-gather plan,
+    short rows with look-back as single-vector default, and a column-tiled matrix (per-vector bias = y)."""
+    rng = np.random.default_rng(33)
+    W = rng.standard_normal((700, 1001), dtype=np.float32)               # odd column count: dword path
+    W4 = rng.standard_normal((300, 512), dtype=np.float32)
+    b_d, b_d4 = rng.standard_normal(700, dtype=np.float32), rng.standard_normal(300, dtype=np.float32)
+    i_d, i_d4 = fpga.create_dense_handle(W.flatten(), *W.shape), fpga.create_dense_handle(W4.flatten(), *W4.shape)
+    sparse = []
+    for rows, cols, nnz, kind in [(4096, 4096, 1700000, "lds window"), (30000, 20000, 300000, "l2 gathers"),
+                                  (200000, 200000, 900000, "short rows"), (150000, 1800000, 1500000, "column tiles")]:
+        r = rng.integers(0, rows, nnz).astype(np.int32)
+        c = rng.integers(0, cols, nnz).astype(np.int32)
+        if kind == "short rows":
+            c = ((r.astype(np.int64) + rng.integers(-50, 50, nnz)) % cols).astype(np.int32)
+        v = rng.random(nnz, dtype=np.float32) - 0.5
+        sparse.append((fpga.create_sparse_handle(r, c, v, rows, cols), rows, cols, r, c, v, kind))
+    fpga.load_matrices()
+    for idx, Wd, bd in ((i_d, W, b_d), (i_d4, W4, b_d4)):
+        rows, cols = Wd.shape
+        for nv in (2, 3, 8, 13):
+            xb = rng.standard_normal(nv * cols, dtype=np.float32)
+            yb = fpga.linear(idx, xb, bd)
+            assert yb.shape == (nv * rows,)
+            for k in range(nv):
+                assert np.array_equal(yb[k * rows:(k + 1) * rows], fpga.linear(idx, xb[k * cols:(k + 1) * cols], bd))
+    for idx, rows, cols, r, c, v, kind in sparse:
+        info = fpga.matrix_info(idx)
+        if kind == "lds window":
+            assert info["lds_bytes"] > 0
+        if kind == "column tiles":
+            assert info["col_tiles"] == 2
+        b = rng.standard_normal(rows, dtype=np.float32)
+        tiles = prepared_tiles(info, r, c, v, rows, cols)
+        for nv in (2, 4, 7):
+            xb = rng.standard_normal(nv * cols, dtype=np.float32)
+            yb = fpga.linear(idx, xb, b)
+            for k in range(nv):
+                xk = xb[k * cols:(k + 1) * cols]
+                y64, mag = csr_truth(r, c, v, rows, xk, b, 1.0, 1.0)
+                assert bwd_err(yb[k * rows:(k + 1) * rows], y64, mag) < TOL, (kind, nv, k)
+                # vectors that went through a batched pass (all but the odd last one) follow the fix-up variant
+                batched = k < nv - (nv % 2)
+                ye = emulate_tiles(tiles, xk, b, 1.0, 1.0, rows, 0 if batched else info["carry_lookback"])
+                assert np.array_equal(yb[k * rows:(k + 1) * rows].view(np.uint32), ye.view(np.uint32)), (kind, nv, k)
 
 
 @pytest.mark.parametrize("alpha,beta", [(ALPHA_HOST, BETA_HOST), (1.0, 0.0), (0.0, 1.0), (-1.5, 0.5)])
