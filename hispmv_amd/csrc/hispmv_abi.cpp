@@ -66,10 +66,16 @@ struct hispmv_ctx {
     std::vector<std::unique_ptr<Matrix>> mats;
     int selected = -1;
     int64_t arena_budget = 0, arena_used = 0;
-    float *d_x = nullptr, *d_bias = nullptr, *d_y = nullptr;
-    int64_t cap_x = 0, cap_bias = 0, cap_y = 0;
+    float *d_x = nullptr, *d_y = nullptr;     // device vectors of run_kernel / linear: [x | bias] and y
+    int64_t cap_x = 0, cap_y = 0;
     int64_t col_tile_bytes = 4 << 20;   // x bytes per column tile for scattered matrices (HISPMV_COL_TILE_BYTES)
-    int* d_err = nullptr;        // set by a kernel whose bounded carry wait expired
+    int* h_err = nullptr;        // pinned, device-mapped word set by a kernel whose bounded carry wait expired
+    int* d_err = nullptr;        //   (its device address): read on the host after a stream sync, no copy
+    // run_kernel / linear with host vectors: x and bias are gathered in one pinned block and go up in ONE copy, y comes
+    // back through pinned memory too (pageable hipMemcpyAsync stages and synchronises per call: 3 copies + the error word
+    // cost ~65 us around a 20 us kernel)
+    float* h_stage = nullptr;
+    int64_t cap_stage = 0;
     // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
     // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
     // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.
@@ -108,10 +114,10 @@ int64_t sparse_device_bytes(const SliceStream& st) {
 
 // A bounded in-kernel wait that expired leaves 1 in the context's error word.
 int check_device_error(hispmv_ctx* c) {
-    int flag = 0;
-    HIP_TRY(c, hipMemcpy(&flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    // callers have synchronised the stream the kernels ran on; the word lives in host memory
+    const int flag = *(volatile int*)c->h_err;
     if (flag) {
-        (void)hipMemset(c->d_err, 0, sizeof(int));
+        *(volatile int*)c->h_err = 0;
         return fail(c, HISPMV_EDEVICE, "carry hand-off between slices timed out (lost or overlapping launch on one handle)");
     }
     return HISPMV_OK;
@@ -330,8 +336,9 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_ARENA_BYTES")) { long long v = std::atoll(env); if (v > 0) c->arena_budget = v; }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(nullptr, e, "hipStreamCreate");
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return hip_fail(nullptr, e, "hipEventCreate");
-    if ((e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(int))) != hipSuccess)
-        return hip_fail(nullptr, e, "hipMalloc(err flag)");
+    if ((e = hipHostMalloc((void**)&c->h_err, sizeof(int), hipHostMallocMapped)) != hipSuccess) return hip_fail(nullptr, e, "hipHostMalloc(err flag)");
+    *c->h_err = 0;
+    if ((e = hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0)) != hipSuccess) return hip_fail(nullptr, e, "hipHostGetDevicePointer(err flag)");
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : 2;
@@ -346,9 +353,9 @@ HISPMV_API void hispmv_destroy(hispmv_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& m : c->mats) free_matrix_device(*m);
     if (c->d_x) (void)hipFree(c->d_x);
-    if (c->d_bias) (void)hipFree(c->d_bias);
     if (c->d_y) (void)hipFree(c->d_y);
-    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -536,17 +543,36 @@ static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t nu
                             float* y, float alpha, float beta) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure_vec(c, &c->d_x, &c->cap_x, (int64_t)m.cols * num_vecs)) != HISPMV_OK) return rc;
-    if ((rc = ensure_vec(c, &c->d_bias, &c->cap_bias, m.rows)) != HISPMV_OK) return rc;
-    if ((rc = ensure_vec(c, &c->d_y, &c->cap_y, (int64_t)m.rows * num_vecs)) != HISPMV_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_x, x, (size_t)m.cols * num_vecs * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (beta != 0.0f)
-        HIP_TRY(c, hipMemcpyAsync(c->d_bias, bias, (size_t)m.rows * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    // device side: [x (num_vecs * cols) | bias (rows)] in one block, y in another
+    const int64_t nx = (((int64_t)m.cols * num_vecs + 63) / 64) * 64, nb = m.rows, ny = (int64_t)m.rows * num_vecs;
+    if ((rc = ensure_vec(c, &c->d_x, &c->cap_x, nx + nb)) != HISPMV_OK) return rc;
+    if ((rc = ensure_vec(c, &c->d_y, &c->cap_y, ny)) != HISPMV_OK) return rc;
+    float* const d_x = c->d_x;
+    float* const d_bias = c->d_x + nx;
+    const size_t bx = (size_t)m.cols * num_vecs * sizeof(float), bb = (size_t)nb * sizeof(float), by = (size_t)ny * sizeof(float);
+    const bool staged = (nx + nb + ny) * (int64_t)sizeof(float) <= (8 << 20);     // small vectors: through pinned memory
+    if (staged) {
+        if (nx + nb + ny > c->cap_stage) {
+            if (c->h_stage) (void)hipHostFree(c->h_stage);
+            c->h_stage = nullptr; c->cap_stage = 0;
+            const int64_t want = std::max<int64_t>(nx + nb + ny, 1 << 16);
+            HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, (size_t)want * sizeof(float), hipHostMallocDefault));
+            c->cap_stage = want;
+        }
+        std::memcpy(c->h_stage, x, bx);
+        if (beta != 0.0f) std::memcpy(c->h_stage + nx, bias, bb);
+        HIP_TRY(c, hipMemcpyAsync(d_x, c->h_stage, beta != 0.0f ? (size_t)nx * sizeof(float) + bb : bx, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(d_x, x, bx, hipMemcpyHostToDevice, c->stream));
+        if (beta != 0.0f) HIP_TRY(c, hipMemcpyAsync(d_bias, bias, bb, hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if ((rc = launch_matrix_vectors(c, m, num_vecs, c->d_x, c->d_bias, c->d_y, alpha, beta, c->stream)) != HISPMV_OK) return rc;
+    if ((rc = launch_matrix_vectors(c, m, num_vecs, d_x, d_bias, c->d_y, alpha, beta, c->stream)) != HISPMV_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(y, c->d_y, (size_t)m.rows * num_vecs * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    float* const h_y = staged ? c->h_stage + nx + nb : y;
+    HIP_TRY(c, hipMemcpyAsync(h_y, c->d_y, by, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (staged) std::memcpy(y, h_y, by);
     if (hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1) != hipSuccess) c->last_ms = -1.0f;
     return check_device_error(c);
 }
