@@ -302,6 +302,17 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+HISPMV_API int hispmv_boundary_pack(const float* const* d_last, const float* d_mask, float* d_send, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!d_last || !d_mask || !d_send))) return HISPMV_EINVAL;
+    return launch_boundary_pack(d_last, d_mask, d_send, n, (hipStream_t)stream) == hipSuccess ? HISPMV_OK : HISPMV_EDEVICE;
+}
+
+HISPMV_API int hispmv_boundary_apply(float* const* d_first, const float* d_recv, const float* d_weights, int32_t n,
+                                     int32_t world, void* stream) {
+    if (n < 0 || world < 1 || (n > 0 && (!d_first || !d_recv || !d_weights))) return HISPMV_EINVAL;
+    return launch_boundary_apply(d_first, d_recv, d_weights, n, world, (hipStream_t)stream) == hipSuccess ? HISPMV_OK : HISPMV_EDEVICE;
+}
+
 HISPMV_API const char* hispmv_version(void) { return "hispmv-amd 0.1.0 gfx950"; }
 
 HISPMV_API const char* hispmv_last_error(const hispmv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }

@@ -66,4 +66,9 @@ hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* 
 hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64_t vecs, const float* x, const float* bias,
                                float* y, float alpha, float beta, hipStream_t stream);
 
+// Multi-GPU boundary rows (hispmv.h: hispmv_boundary_pack / hispmv_boundary_apply).
+hipError_t launch_boundary_pack(const float* const* last, const float* mask, float* send, int n, hipStream_t stream);
+hipError_t launch_boundary_apply(float* const* first, const float* recv, const float* weights, int n, int world,
+                                 hipStream_t stream);
+
 }  // namespace hispmv

@@ -768,4 +768,35 @@ hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Multi-GPU boundary rows: the two tiny launches around the all-gather of tails (hispmv.h, hispmv_amd/dist.py).
+// ---------------------------------------------------------------------------
+__global__ void boundary_pack_kernel(const float* const* __restrict__ last, const float* __restrict__ mask,
+                                     float* __restrict__ send, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) send[i] = last[i] ? mask[i] * *last[i] : 0.0f;
+}
+
+__global__ void boundary_apply_kernel(float* const* __restrict__ first, const float* __restrict__ recv,
+                                      const float* __restrict__ weights, int n, int world) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !first[i]) return;
+    float s = 0.0f;
+    for (int r = 0; r < world; ++r) s += recv[(size_t)r * n + i] * weights[(size_t)i * world + r];
+    *first[i] += s;
+}
+
+hipError_t launch_boundary_pack(const float* const* last, const float* mask, float* send, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(boundary_pack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, last, mask, send, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_boundary_apply(float* const* first, const float* recv, const float* weights, int n, int world,
+                                 hipStream_t stream) {
+    if (n <= 0 || world <= 0) return hipSuccess;
+    hipLaunchKernelGGL(boundary_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, first, recv, weights, n, world);
+    return hipGetLastError();
+}
+
 }  // namespace hispmv

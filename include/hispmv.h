@@ -108,6 +108,18 @@ float hispmv_last_kernel_ms(hispmv_ctx* ctx);
 float hispmv_time_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, const float* d_bias, float* d_y,
                          float alpha, float beta, int reps);
 
+/* ---- multi-GPU boundary rows (no reference counterpart: the reference is single-device) ----
+ * A matrix whose element sequence is split over ranks has at most one row cut at each rank boundary.  Per step
+ * every rank publishes, for each of its n matrices, the last entry of its local y when that row continues on the
+ * next rank (its "tail"), the tails are all-gathered (torch.distributed / RCCL), and each rank adds the chain of
+ * tails that feeds its first row.  These two launches are the device side of that step on `stream`:
+ *   pack:  send[i] = mask[i] * *last[i]                                   (last[i] may be NULL: 0)
+ *   apply: *first[i] += sum_r recv[r*n + i] * weights[i*world + r]        (first[i] NULL: nothing), r ascending
+ * All pointers are device pointers (last/first: device arrays of n device pointers). */
+int hispmv_boundary_pack(const float* const* d_last, const float* d_mask, float* d_send, int32_t n, void* stream);
+int hispmv_boundary_apply(float* const* d_first, const float* d_recv, const float* d_weights, int32_t n, int32_t world,
+                          void* stream);
+
 /* ---- getters (HiSpmvHandle getters, spmv-helper.cpp:752-810) ------------------------------------ */
 typedef struct hispmv_matrix_info {
     int32_t rows, cols;
