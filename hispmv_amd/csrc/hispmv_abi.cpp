@@ -352,7 +352,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0)) != hipSuccess) return hip_fail(nullptr, e, "hipHostGetDevicePointer(err flag)");
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
-        c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : 2;
+        c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = c.release();
     return HISPMV_OK;
@@ -509,27 +509,27 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.n_slices = ns; d.n_groups = (ns + p.plan.group_slices - 1) / p.plan.group_slices;
                 d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads; d.lds_floats = p.plan.lds_floats;
                 d.ytile_floats = std::min(kSliceElems, (max_rows + 63) & ~63);
-                if ((size_t)(d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 + (size_t)d.group_slices * 8 > 160 * 1024 - 256)
-                    return fail(c, HISPMV_EINVAL, "internal: launch plan exceeds the LDS of a CU");
+                const size_t lds_plain = (size_t)(d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4;
+                if (lds_plain > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: launch plan exceeds the LDS of a CU");
+                const bool mailbox_fits = lds_plain + (size_t)d.group_slices * 8 <= 160 * 1024 - 256;   // look-back: 8 B per slice of a group
                 d.n_fix_short = (int32_t)p.fix_short.size(); d.n_fix_long = (int32_t)p.fix_long.size();
                 d.rows = m.rows; d.cols = m.cols;
                 // co-residency of the whole grid: workgroups per CU by LDS and waves (conservative: <= 4 blocks,
                 // <= 16 waves per CU; MI355X_MICROARCH.md "Residency")
-                const int lds_b = std::max(1, (d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4 + 64);
+                const int lds_b = std::max(1, (int)lds_plain + 64);
                 const int per_cu = std::max(1, std::min({4, (160 * 1024) / lds_b, 16 / (d.block_threads / 64)}));
-                // ... and every slice must be in flight at once (one slice per wavefront): if a wavefront had a second
-                // slice, a workgroup's first slice would wait for the predecessor's LAST slice, which waits for that
-                // workgroup's first slice, ... -- one serial chain through the whole grid (measured: 14x slower).
-                // ("resident" also asks for one slice per wavefront: with longer per-wave chunks the look-back is correct
-                // -- chains inside the group go through an LDS mailbox, the chain that crosses into the group is
-                // deferred to the end -- but the wavefronts of a workgroup then wait on each other every round and
-                // the big matrices lose more than the 5 us fix-up launch costs: PFlow 77.6 vs 70.8 us)
-                const bool resident = d.n_groups <= (int64_t)c->n_cus * per_cu && d.group_slices <= d.block_threads / 64;
+                const bool resident = d.n_groups <= (int64_t)c->n_cus * per_cu;
+                const bool one_round = d.group_slices <= d.block_threads / 64;
                 // carry_mode: 0 fix-up launch; 1 look-back for every plan, workgroups in blockIdx order (relies on the
                 // dispatcher starting workgroups in increasing id order -- observed, not contractual; the wait is
                 // bounded and reports instead of hanging); 3 the same with start-order tickets (contract-safe);
-                // 2 (auto) look-back when the whole grid is co-resident, fix-up otherwise
-                d.lookback = c->carry_mode == 1 || c->carry_mode == 3 || (c->carry_mode == 2 && resident);
+                // 2 (auto) look-back when the whole grid is co-resident (every workgroup is running, so waiting for an
+                // earlier slice cannot deadlock) AND every wavefront has one slice (small matrices, where the second
+                // launch costs as much as the kernel), fix-up otherwise; 5 ("resident") look-back for every co-resident
+                // grid: correct, but measured slower than main kernel + fix-up launch on the large matrices
+                // (PFlow_742 71.6 vs 65.2 us, TSOPF 35.5 vs 33.6: wavefronts that run ahead wait for slower neighbours)
+                d.lookback = (c->carry_mode == 1 || c->carry_mode == 3 || (c->carry_mode == 2 && resident && one_round) ||
+                              (c->carry_mode == 5 && resident)) && mailbox_fits;
                 d.use_ticket = c->carry_mode == 3;
             }
         }

@@ -18,6 +18,7 @@
 
 #include "hispmv_format.h"
 #include "hispmv_kernels.h"
+#include <cstdlib>
 
 namespace hispmv {
 
@@ -68,7 +69,18 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
 // Slices of this workgroup (index >= first) are read from the group's LDS mailbox `local` (a neighbour
 // wavefront published them a moment ago: ~100 cycles instead of an L2-bypassing round trip per slice), slices
 // of earlier workgroups from the global granules.
-__device__ __forceinline__ float lookback_chain(const LookbackArgs& lb, const volatile unsigned long long* local,
+// The group's mailbox lives in LDS: an explicit address-space-3 pointer with relaxed workgroup-scope atomics compiles
+// to ds_write_b64 / ds_read_b64.  (A `volatile unsigned long long*` became FLAT accesses with sc0 sc1 and an
+// s_waitcnt vmcnt(0) after every store -- which also waited for the next slice's prefetch: +15 us on PFlow_742.)
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+__device__ __forceinline__ void mbox_store(lds_u64* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned long long mbox_load(lds_u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ float lookback_chain(const LookbackArgs& lb, lds_u64* local,
                                                 long long first, long long cur, int chain_len, int lane) {
     float part = 0.0f;
     for (int k = lane; k < chain_len; k += 64) {
@@ -76,10 +88,10 @@ __device__ __forceinline__ float lookback_chain(const LookbackArgs& lb, const vo
         unsigned long long v;
         int spins = 0;
         if (src >= first) {
-            v = local[src - first];
+            v = mbox_load(local + (src - first));
             while ((unsigned)(v >> 32) != lb.epoch && spins < kLookbackSpinMax) {
                 __builtin_amdgcn_s_sleep(1);
-                v = local[src - first];
+                v = mbox_load(local + (src - first));
                 ++spins;
             }
         } else {
@@ -138,8 +150,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     float* const ytile = xs + (USE_LDS ? lds_floats : 0) + wave * ytile_floats;
     // look-back mailbox of the group: one {carry, launch tag} per slice, published by the wavefront that owns it
-    volatile unsigned long long* const mbox =
-        (volatile unsigned long long*)(xs + (USE_LDS ? lds_floats : 0) + (blockDim.x >> 6) * ytile_floats);
+    lds_u64* const mbox = (lds_u64*)(xs + (USE_LDS ? lds_floats : 0) + (blockDim.x >> 6) * ytile_floats);
     long long group = blockIdx.x;
     if (LOOKBACK) {
         // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     }
 
     if (LOOKBACK) {
-        for (int i = threadIdx.x; i < group_slices; i += blockDim.x) mbox[i] = 0ull;   // tag 0 = not published
+        for (int i = threadIdx.x; i < group_slices; i += blockDim.x) mbox_store(mbox + i, 0ull);   // tag 0 = not published
         if (!USE_LDS) __syncthreads();
     }
     // LoadB: stage the x fragments of this group (runs of 64-byte blocks its slices touch) into LDS; the
@@ -207,9 +218,9 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     // the group a slice's predecessors are handled in the same or an earlier round; the previous workgroup's last
     // slice is handled in ITS last round -- waiting for it mid-loop would stall this wavefront for the whole
     // kernel (and, chained through every workgroup, serialise the grid: measured 14x).
-    long long def_slice = -1;
-    int def_row = 0, def_len = 0;
-    float def_t = 0.0f, def_b = 0.0f;
+    long long def_slice = -1, pend_slice = -1;
+    int def_row = 0, def_len = 0, pend_row = 0, pend_len = 0;
+    float def_t = 0.0f, def_b = 0.0f, pend_t = 0.0f, pend_b = 0.0f;
 
     while (slice < last) {
         int row = __builtin_amdgcn_readfirstlane(h.x);
@@ -305,28 +316,33 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
             t1[j] = e0 ? p1[j] : cin + (p0[j] + p1[j]);
         }
 
-        float chain = 0.0f;
-        bool deferred = false;
+        bool deferred = false, rolling = false;
         if (LOOKBACK) {
             // publish this slice's open partial sum as ONE 8-byte {value, launch tag} granule ...
             if (lane == 0) {
                 const unsigned long long granule = ((unsigned long long)lb.epoch << 32) | (unsigned)f2i(carry_step);
-                mbox[cur - first] = granule;
+                mbox_store(mbox + (cur - first), granule);
                 __hip_atomic_store(lb.gran + cur, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // ... and collect the parts of the first row that earlier slices hold (rows "shared" between
-            // wavefronts): lane k polls the granule of slice (s - chain_len + k); fixed summation order.
-            deferred = chain_len > (int)(cur - first);     // the chain leaves this group: resolve after the loop
-            if (chain_len > 0 && !deferred) {
-                chain = lookback_chain(lb, mbox, first, cur, chain_len, lane);
-#pragma unroll
-                for (int j = 0; j < kSliceSteps; ++j) {
-                    const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
-                    if (e0 && r0[j] == row_first) t0[j] += chain;
-                    else if (!e0 && e1 && r0[j] == row_first) t1[j] += chain;
+            // ... and finish the cut row of this wavefront's PREVIOUS slice: the slices it reaches back to were
+            // taken by the neighbouring wavefronts a whole iteration ago, so their carries are usually there.
+            // (Resolving the row in its own iteration made every wavefront wait for its left neighbour's scan each
+            // round: lockstep.  One iteration of slack removes most of it, yet on long per-wave chunks a wavefront that
+            // runs ahead still waits for the slower ones, and the variant itself is ~5 us slower than the fix-up
+            // variant's main kernel on PFlow_742 -- so large matrices keep the fix-up launch, hispmv_abi.cpp.)
+            if (pend_slice >= 0) {
+                const float chain = lookback_chain(lb, mbox, first, pend_slice, pend_len, lane);
+                if (lane == 0) {
+                    const float t = pend_t + chain;
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * t + beta * pend_b : alpha * t), ry,
+                                                          (unsigned)pend_row << 2, 0, 0);
                 }
+                pend_slice = -1;
             }
+            deferred = chain_len > (int)(cur - first);     // the chain leaves this group: resolved after the loop
+            rolling = chain_len > 0 && !deferred;          // inside the group: resolved one iteration later
             if (deferred) { def_slice = cur; def_row = row_first; def_len = chain_len; }
+            if (rolling) { pend_slice = cur; pend_row = row_first; pend_len = chain_len; }
         }
 
         // AccumBuffer -> Compute_C: the row totals go through this wavefront's LDS tile (one ds_write per row
@@ -338,21 +354,31 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
             if (e0) ytile[r0[j] - row_first] = t0[j];
             if (e1) ytile[r0[j] - row_first + (e0 ? 1 : 0)] = t1[j];
         }
+        const bool held = LOOKBACK && (deferred || rolling);   // the slice's first row is stored later, with its chain
         for (int i = lane; i < n_rows; i += 64) {
             const float t = ytile[i];
-            // the first row of a deferred slice is written after the loop, once its chain is known
-            const unsigned dst = (LOOKBACK && deferred && i == 0) ? kNoAccess : (unsigned)(row_first + i) << 2;
+            const unsigned dst = (held && i == 0) ? kNoAccess : (unsigned)(row_first + i) << 2;
             if (HAS_BETA) {
                 const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
                               : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(row_first + i) << 2, 0, 0));
                 if (LOOKBACK && deferred && i == 0) { def_t = t; def_b = b; }
+                if (LOOKBACK && rolling && i == 0) { pend_t = t; pend_b = b; }
                 __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, dst, 0, 0);
             } else {
                 if (LOOKBACK && deferred && i == 0) def_t = t;
+                if (LOOKBACK && rolling && i == 0) pend_t = t;
                 __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, dst, 0, 0);
             }
         }
         if (!LOOKBACK && lane == 0) carry[cur] = carry_step;
+    }
+    if (LOOKBACK && pend_slice >= 0) {    // the cut row of this wavefront's last slice
+        const float chain = lookback_chain(lb, mbox, first, pend_slice, pend_len, lane);
+        if (lane == 0) {
+            const float t = pend_t + chain;
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * t + beta * pend_b : alpha * t), ry,
+                                                  (unsigned)pend_row << 2, 0, 0);
+        }
     }
     if (LOOKBACK && def_slice >= 0) {     // wave-uniform: the row that crosses into this group from the previous one
         const float chain = lookback_chain(lb, mbox, first, def_slice, def_len, lane);

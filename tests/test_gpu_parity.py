@@ -95,7 +95,7 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
     assert info["nnz"] == g["ref_col_idx"].size and info["loaded"] == 1 and not info["is_dense"]
 
 
-@pytest.mark.parametrize("carry,mode", [("lookback", 1), ("fixup", 0), ("auto", None)])
+@pytest.mark.parametrize("carry,mode", [("lookback", 1), ("fixup", 0), ("resident", None), ("auto", None)])
 def test_both_carry_variants_match_their_wavefront_model(pyhispmv_mod, monkeypatch, carry, mode):
     """Rows shared between slices: the two-launch fix-up variant (default) and the single-launch
     look-back (HISPMV_CARRY=lookback) each reproduce their CPU model bit for bit, on a matrix with
