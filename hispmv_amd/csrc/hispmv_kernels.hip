@@ -288,6 +288,16 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
             p1[j] = i2f((int)w[j].z) * x1[j];
             ends |= ((w[j].y >> 31) << (2 * j)) | ((w[j].w >> 31) << (2 * j + 1));
         }
+        // hipcc would hoist the prefetch above the products (its results land in fresh registers); the waits for the
+        // gathers, placed after the point where the three gather paths merge, then count conservatively and wait for
+        // the prefetch as well.  Pin the products here and keep memory operations from crossing (PFlow_742 65.3 ->
+        // 62.4 us; not in the look-back variant: its one-slice-per-wavefront launches have no next slice to request
+        // and lose 0.4 us to the barrier).
+        if (!LOOKBACK) {
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) asm volatile("" : "+v"(p0[j]), "+v"(p1[j]));
+            asm volatile("" ::: "memory");
+        }
         const long long cur = slice;
         slice += n_waves;
         if (slice < last) {
