@@ -19,8 +19,9 @@ dst.mkdir(exist_ok=True)
 
 
 def first(pattern):
-    g = sorted(glob.glob(str(src / pattern), recursive=True))
-    return g[0] if g else None
+    import os
+    g = sorted(glob.glob(str(src / pattern), recursive=True), key=os.path.getmtime)   # gpurun merges runs: newest wins
+    return g[-1] if g else None
 
 
 out = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `tools/profile_round.sh " + tag + "` (bench.py --steps 5 --warmup 1, 20-matrix set)", ""]
