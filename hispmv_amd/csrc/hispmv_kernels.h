@@ -41,6 +41,18 @@ struct LookbackArgs {
     int use_ticket;
 };
 
+// Multi-matrix launch (hispmv_spmv_device_batch): device table entry per matrix part ...
+struct MultiEntry {
+    const uint64_t* words; const int4* hdr; const int4* groups; const int4* frags;
+    const float* x; const float* bias; float* y; float* carry;
+    long long n_slices;
+    int32_t group_slices, lds_floats, ytile_floats, cols, rows, pad;
+};
+struct MultiFixEntry { const int4* fix; const float* carry; float* y; int32_t n, pad; };
+// ... and, as a kernel argument, where each entry's workgroups begin in the grid (begin[n] = grid size)
+constexpr int kMultiMax = 32;
+struct MultiPrefix { int32_t n, pad; long long begin[kMultiMax + 1]; };
+
 constexpr int kFixShortMax = 32;
 constexpr int kMaxBatch = 4;                // vectors one pass of the batched slice kernel takes (carry holds kMaxBatch * n_slices)
 
@@ -58,6 +70,15 @@ hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, f
 int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs, float beta);
 hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, const float* bias, int bias_stride, float* y,
                                float alpha, float beta, hipStream_t stream);
+
+// Multi-matrix launch: `n` (<= kMultiMax) matrix parts with the same workgroup size in one grid, each writing carry[]
+// for rows cut by slice boundaries; `d_table` is the device copy of their MultiEntry descriptors (the caller owns and
+// caches it).  beta == 0 selects the variant without bias.  launch_fixup_multi then finishes the cut rows of `n` parts
+// (any workgroup sizes) in one launch; parts with fix_long rows get their own extra launch.
+hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const MultiEntry* d_table,
+                             float alpha, float beta, hipStream_t stream);
+hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const* ys, int n, const MultiFixEntry* d_fix_table,
+                              float alpha, hipStream_t stream);
 
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,

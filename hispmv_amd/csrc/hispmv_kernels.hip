@@ -18,6 +18,7 @@
 
 #include "hispmv_format.h"
 #include "hispmv_kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace hispmv {
@@ -128,13 +129,14 @@ __device__ __forceinline__ uint4 load_words(const uint4* p) {
     return uint4{v.x, v.y, v.z, v.w};
 }
 
+// The work of one workgroup on group `group` of a matrix (the body of the slice kernels below).
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
-__global__ __launch_bounds__(1024) void spmv_slices_kernel(
+__device__ __forceinline__ void slices_body(
     const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags,
     const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int ytile_floats, int cols, int rows, LookbackArgs lb) {
+    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group) {
     // LDS: [x window: lds_floats][row totals of the slice in flight: ytile_floats per wavefront]
     extern __shared__ float xs[];
     // x, bias and y are reached through buffer descriptors: 32-bit byte offsets instead of 64-bit
@@ -151,7 +153,6 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     float* const ytile = xs + (USE_LDS ? lds_floats : 0) + wave * ytile_floats;
     // look-back mailbox of the group: one {carry, launch tag} per slice, published by the wavefront that owns it
     lds_u64* const mbox = (lds_u64*)(xs + (USE_LDS ? lds_floats : 0) + (blockDim.x >> 6) * ytile_floats);
-    long long group = blockIdx.x;
     if (LOOKBACK) {
         // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
         // may have to wait for belongs to a workgroup that is already running or done -- the carry
@@ -400,6 +401,50 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     }
 }
 
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
+__global__ __launch_bounds__(1024) void spmv_slices_kernel(
+    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
+    float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
+    int lds_floats, int ytile_floats, int cols, int rows, LookbackArgs lb) {
+    slices_body<HAS_BETA, USE_LDS, LOOKBACK>(words, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+                                             lds_floats, ytile_floats, cols, rows, lb, (long long)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Several matrices in ONE launch (hispmv_spmv_device_batch): the grid is the concatenation of the matrices' groups;
+// a workgroup finds its matrix from the prefix of group counts (kernel argument, no memory access), reads that
+// matrix's descriptor from a device table and runs the ordinary body with the fix-up carry variant.  Independent
+// SpMVs -- the 20 matrices of the benchmark set, the heads of a model -- then share launch ramps and tails instead of
+// paying 6-20 us of launch latency each.  All matrices of a launch have the same workgroup size.
+// ---------------------------------------------------------------------------
+template <bool HAS_BETA>
+__global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix,
+                                                                 float alpha, float beta) {
+    int e = 0;
+#pragma unroll 1
+    while (e + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[e + 1]) ++e;
+    const MultiEntry t = table[e];
+    const LookbackArgs lb{};
+    slices_body<HAS_BETA, true, false>((const uint4*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, beta,
+                                       t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb,
+                                       (long long)blockIdx.x - prefix.begin[e]);
+}
+
+// Fix-up of all matrices of a multi launch: thread blocks are concatenated the same way.
+__global__ __launch_bounds__(256) void spmv_fixup_multi_kernel(const MultiFixEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
+    int e = 0;
+#pragma unroll 1
+    while (e + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[e + 1]) ++e;
+    const MultiFixEntry t = table[e];
+    const int i = (int)(blockIdx.x - prefix.begin[e]) * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    const int4 f = t.fix[i];
+    float s = 0.0f;
+    for (int k = 0; k < f.z; ++k) s += t.carry[f.y + k];
+    t.y[f.x] += alpha * s;
+}
+
 // ---------------------------------------------------------------------------
 // Batched slice kernel: NV input vectors per pass over the stream (FpgaHandle::linear with num_vecs > 1; the
 // reference runs its kernel once per vector, fpga_handle.cpp:366-379 -- A is read num_vecs times).  Vector v
@@ -628,6 +673,7 @@ hipError_t prepare_spmv_kernels() {
 
 hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, float* y,
                        float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (m.n_slices > 0) {
         if (m.n_groups <= 0 || m.n_groups > 0x7fffffffLL) return hipErrorInvalidValue;
         LookbackArgs lb{};
@@ -684,6 +730,7 @@ int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs, float beta) {
 
 hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, const float* bias, int bias_stride, float* y,
                                float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (nv != 2 && nv != 4) return hipErrorInvalidValue;
     if (m.n_slices > 0) {
         if (m.n_groups <= 0 || m.n_groups > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -701,6 +748,58 @@ hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, cons
     if (m.n_fix_long > 0)
         hipLaunchKernelGGL(spmv_fixup_long_kernel, dim3((m.n_fix_long + 3) / 4, nv), dim3(256), 0, stream,
                            m.fix_long, m.n_fix_long, m.carry, y, alpha, (long long)m.n_slices, (long long)m.rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const MultiEntry* d_table,
+                             float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
+    if (n <= 0) return hipSuccess;
+    if (n > kMultiMax) return hipErrorInvalidValue;
+    MultiPrefix px{};
+    px.n = n;
+    long long g = 0;
+    size_t lds = 0;
+    const int threads = parts[0]->block_threads;
+    for (int i = 0; i < n; ++i) {
+        const SpmvDeviceMatrix& m = *parts[i];
+        if (m.block_threads != threads || m.n_groups < 0) return hipErrorInvalidValue;
+        px.begin[i] = g; g += m.n_slices > 0 ? m.n_groups : 0;
+        lds = std::max(lds, ((size_t)m.lds_floats + (size_t)m.ytile_floats * (threads / 64)) * sizeof(float));
+    }
+    px.begin[n] = g;
+    if (g > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        raised = true;
+    }
+    if (g > 0) {
+        if (beta != 0.0f) hipLaunchKernelGGL(spmv_slices_multi_kernel<true>, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha, beta);
+        else hipLaunchKernelGGL(spmv_slices_multi_kernel<false>, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha, beta);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const* ys, int n, const MultiFixEntry* d_fix_table,
+                              float alpha, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    if (n > kMultiMax) return hipErrorInvalidValue;
+    MultiPrefix fx{};
+    fx.n = n;
+    long long fb = 0;
+    for (int i = 0; i < n; ++i) { fx.begin[i] = fb; fb += (parts[i]->n_fix_short + 255) / 256; }
+    fx.begin[n] = fb;
+    if (fb > 0) hipLaunchKernelGGL(spmv_fixup_multi_kernel, dim3((unsigned)fb), dim3(256), 0, stream, d_fix_table, fx, alpha);
+    for (int i = 0; i < n; ++i) {
+        const SpmvDeviceMatrix& m = *parts[i];
+        if (m.n_fix_long > 0)
+            hipLaunchKernelGGL(spmv_fixup_long_kernel, dim3((m.n_fix_long + 3) / 4), dim3(256), 0, stream,
+                               m.fix_long, m.n_fix_long, m.carry, ys[i], alpha, 0LL, 0LL);
+    }
     return hipGetLastError();
 }
 
@@ -784,6 +883,7 @@ static void launch_gemv_nv(const float* W, int32_t rows, int32_t cols, const flo
 
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
                        float* y, float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (rows <= 0) return hipSuccess;
     launch_gemv_nv<1>(W, rows, cols, x, bias, y, alpha, beta, stream);
     return hipGetLastError();
@@ -791,6 +891,7 @@ hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* 
 
 hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64_t vecs, const float* x, const float* bias,
                                float* y, float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (rows <= 0) return hipSuccess;
     int64_t k = 0;
     while (k < vecs) {      // 8, 4, 2, 1 vectors per pass over W
@@ -823,6 +924,7 @@ __global__ void boundary_apply_kernel(float* const* __restrict__ first, const fl
 }
 
 hipError_t launch_boundary_pack(const float* const* last, const float* mask, float* send, int n, hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(boundary_pack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, last, mask, send, n);
     return hipGetLastError();
@@ -830,6 +932,7 @@ hipError_t launch_boundary_pack(const float* const* last, const float* mask, flo
 
 hipError_t launch_boundary_apply(float* const* first, const float* recv, const float* weights, int n, int world,
                                  hipStream_t stream) {
+    (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (n <= 0 || world <= 0) return hipSuccess;
     hipLaunchKernelGGL(boundary_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, first, recv, weights, n, world);
     return hipGetLastError();

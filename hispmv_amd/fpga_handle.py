@@ -171,6 +171,23 @@ class FpgaHandle:
         self._check(lib.hispmv_spmv_device(self._ctx, int(matrix_idx), C.c_void_p(d_x), C.c_void_p(d_bias),
                                            C.c_void_p(d_y), float(alpha), float(beta), C.c_void_p(stream)))
 
+    def prepare_batch(self, matrix_idxs, d_xs, d_biases, d_ys):
+        """Argument block for `spmv_device_batch` (host arrays of device pointers), built once and reused."""
+        n = len(matrix_idxs)
+        if not (len(d_xs) == len(d_ys) == n and (d_biases is None or len(d_biases) == n)):
+            raise ValueError("prepare_batch: lists of different length")
+        idx = (C.c_int32 * n)(*[int(i) for i in matrix_idxs])
+        xs = (C.c_void_p * n)(*[int(p) for p in d_xs])
+        bs = (C.c_void_p * n)(*[int(p) for p in d_biases]) if d_biases is not None else None
+        ys = (C.c_void_p * n)(*[int(p) for p in d_ys])
+        return (n, idx, xs, bs, ys)
+
+    def spmv_device_batch(self, batch, alpha: float, beta: float, stream: int = 0) -> None:
+        """n independent SpMVs in as few launches as possible (hispmv_spmv_device_batch): matrices with the same
+        workgroup size share one grid.  `batch` comes from `prepare_batch`.  Asynchronous on `stream`."""
+        n, idx, xs, bs, ys = batch
+        self._check(lib.hispmv_spmv_device_batch(self._ctx, n, idx, xs, bs, ys, float(alpha), float(beta), C.c_void_p(stream)))
+
     def time_device(self, matrix_idx: int, d_x: int, d_bias: int, d_y: int, alpha: float, beta: float,
                     reps: int) -> float:
         ms = lib.hispmv_time_device(self._ctx, int(matrix_idx), C.c_void_p(d_x), C.c_void_p(d_bias),

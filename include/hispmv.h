@@ -103,6 +103,15 @@ int hispmv_synchronize(hispmv_ctx* ctx);
  * measured with HIP events on the launch stream (milliseconds); negative if unavailable. */
 float hispmv_last_kernel_ms(hispmv_ctx* ctx);
 
+/* n independent SpMVs y_i = alpha*A_i*x_i + beta*bias_i on loaded handles idx[i] in as few launches as possible: the
+ * workgroups of all matrices with the same workgroup size share ONE grid (plus one fix-up launch), so small matrices no
+ * longer pay 6-20 us of launch latency each (no reference counterpart: the reference runs one matrix at a time,
+ * fpga_handle.cpp:286-321).  idx, d_x, d_bias, d_y are HOST arrays of n entries (device pointers inside); the y_i must
+ * be distinct.  Rows cut by slice boundaries always take the fix-up variant here, so a result may differ in the last
+ * bit from hispmv_spmv_device on a matrix whose single launch uses the look-back variant.  Asynchronous on `stream`. */
+int hispmv_spmv_device_batch(hispmv_ctx* ctx, int32_t n, const int32_t* idx, const float* const* d_x,
+                             const float* const* d_bias, float* const* d_y, float alpha, float beta, void* stream);
+
 /* Time `reps` back-to-back launches of matrix_idx on the context stream with HIP events
  * (kernel-only, the reference's convention: spmv-helper.cpp:1030-1035).  Returns ms per launch. */
 float hispmv_time_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, const float* d_bias, float* d_y,
