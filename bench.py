@@ -325,7 +325,8 @@ def main():
             "hbm_gbs_algorithmic": round(total_bytes / t_wall / 1e9, 1),
             "hbm_pct_of_peak": round(100 * total_bytes / t_wall / 1e9 / (HBM_PEAK_GBS * world), 2),
             "geomean_gflops_per_matrix": None if geo is None else round(geo, 2),
-            "roofline": {"bound": "hbm", "kernel": "spmv_slices_kernel (+ carry fix-up launches)",
+            "roofline": {"bound": "hbm", "kernel": ("spmv_slices_multi_kernel (matrices of one workgroup size share a grid; + one fix-up launch per round)"
+                                                    if args.launch == "batch" else "spmv_slices_kernel (+ carry fix-up launches)"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch_avg": int(bytes_step / len(mats)),
