@@ -8,7 +8,7 @@ namespace hispmv {
 
 struct SpmvDeviceMatrix {
     const uint64_t* words = nullptr;    // n_slices * kSliceElems packed elements
-    const int4* hdr = nullptr;          // n_slices x {row_base, chain_len, x_base, x_span}
+    const int4* hdr = nullptr;          // n_slices x {row_base, chain_len, rows ending in the slice, 1 if elements lie outside the x window}
     const int4* fix_short = nullptr;    // {row, first_slice, len, 0}, len <= kFixShortMax
     const int4* fix_long = nullptr;     // same, len > kFixShortMax
     const int4* groups = nullptr;       // n_groups x {frag_begin, frag_count, lds_floats, 0}: the x fragments a workgroup stages

@@ -12,7 +12,9 @@
 //   rows "shared" between PEs                       -> rows cut by a slice boundary: each slice hands its
 //                                                      open partial sum to carry[slice]; the fix-up kernel
 //                                                      adds the chain to the owner row in fixed order
-//                                                      (bitwise reproducible, no float atomics)
+//                                                      (bitwise reproducible, no float atomics); small
+//                                                      co-resident launches merge them in-kernel (look-back)
+// Variants: NV vectors per pass (batched linear), several matrices per launch (hispmv_spmv_device_batch).
 // Bandwidth-bound gather: no MFMA.  Roofline and byte accounting: DESIGN.md.
 #include <hip/hip_runtime.h>
 
@@ -113,12 +115,14 @@ __device__ __forceinline__ float lookback_chain(const LookbackArgs& lb, lds_u64*
 // ---------------------------------------------------------------------------
 // Slice kernel.  One workgroup owns a GROUP of consecutive slices (the analogue of a PE group fed by
 // one x window, LoadB base_functions.cpp:105-150); its wavefronts take the group's slices round-robin.
-//   phase 0 (group): the group's x window [x_base, x_base+x_span) is staged into LDS with coalesced
-//            16-byte loads when it fits (USE_LDS and span <= lds_floats); otherwise x is gathered from L2.
-//   phase 1 (slice): 8 x global_load_dwordx4 bring the 8 KiB slice; 16 gathers (ds_read_b32 or global).
-//   phase 2: 8 steps of pair-combine + DPP segmented scan; row totals stay in registers.
-//   phase 3: all bias loads of the slice, then all y stores (alpha*total + beta*bias), then carry.
-// No global store sits between a slice's loads, so hipcc keeps them all in flight together.
+//   group, once: the group's x FRAGMENTS (runs of the 64-byte blocks of x its slices touch, hispmv_plan.h) are
+//            staged into LDS with coalesced 16-byte loads; the words of such a group index that window.  A group
+//            without fragments gathers x through L2; single elements outside the window do too (kGlobalColBit).
+//   slice:   8 x global_load_dwordx4 (non-temporal) bring the 8 KiB slice -- requested one iteration ahead;
+//            row ids from ballots; 16 gathers (ds_read_b32 or buffer loads) + the bias of the slice's rows;
+//            products; next slice requested; 8 steps of pair-combine + DPP segmented scan (totals in registers);
+//            row totals -> this wavefront's LDS tile -> coalesced y = alpha*total + beta*bias stores; the partial
+//            sum left open goes to carry[slice] (fix-up launch) or to the look-back mailbox/granule.
 // ---------------------------------------------------------------------------
 // One 16-byte piece of the packed stream.  The stream is read exactly once per launch: the non-temporal
 // hint keeps it from evicting x, y and the fragment tables from L2 (measured: -5..8 % kernel time on
