@@ -47,7 +47,7 @@ struct Matrix {
     std::vector<Part> parts;
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0;
-    int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0;
+    int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
     float* d_dense = nullptr;
     std::vector<void*> allocs;
 };
@@ -202,31 +202,61 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
     // Column tiling when the whole-matrix plan has to gather x through L2:
     //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
     //  * x larger than an XCD's L2: L2-sized tiles.
-    int32_t tw = 0;
+    int32_t tw = 0, tbase = 0;
     const LaunchPlan& whole = m->parts[0].plan;
+    // columns the matrix actually uses: a block of a larger matrix (a rank's shard: x is replicated at full length)
+    // is tiled over ITS column range, not over the width of x; the 0.1 % of elements at either end do not count
+    // (a shard also holds a few rows of the next block) -- they go to the first / last tile, which are open-ended
+    int32_t cmin = INT32_MAX, cmax = -1;
+    const int64_t nnz_all = csr.nnz();
+#pragma omp parallel for reduction(min : cmin) reduction(max : cmax) schedule(static)
+    for (int64_t k = 0; k < nnz_all; ++k) { cmin = std::min(cmin, csr.col[(size_t)k]); cmax = std::max(cmax, csr.col[(size_t)k]); }
+    if (cmax >= cmin) {
+        constexpr int kBins = 1024;
+        const int64_t bin_w = ((int64_t)cmax - cmin) / kBins + 1;
+        std::vector<int64_t> hist(kBins, 0);
+#pragma omp parallel
+        {
+            std::vector<int64_t> local(kBins, 0);
+#pragma omp for schedule(static) nowait
+            for (int64_t k = 0; k < nnz_all; ++k) local[(size_t)((csr.col[(size_t)k] - cmin) / bin_w)]++;
+#pragma omp critical
+            for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
+        }
+        const int64_t cut = nnz_all / 1000;
+        int lo = 0, hi = kBins - 1;
+        for (int64_t acc = 0; lo < hi && acc + hist[(size_t)lo] <= cut; ++lo) acc += hist[(size_t)lo];
+        for (int64_t acc = 0; hi > lo && acc + hist[(size_t)hi] <= cut; --hi) acc += hist[(size_t)hi];
+        const int64_t qlo = cmin + lo * bin_w, qhi = std::min<int64_t>(cmax, cmin + (hi + 1) * bin_w - 1);
+        cmin = (int32_t)qlo; cmax = (int32_t)qhi;
+    }
+    const int32_t used = cmax >= cmin ? cmax - (cmin & ~63) + 1 : 0;
     // (a window that leaves more than a tenth of the gathers to L2 counts as "does not fit" here)
     const bool spilling = whole.lds_floats > 0 && whole.global_elems * 10 > m->parts[0].st.n_slices * (int64_t)kSliceElems;
-    if (whole.lds_floats == 0 || spilling) {
-        if (csr.cols <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096)
-            tw = ((csr.cols + 1) / 2 + 63) & ~63;
-        else if (whole.lds_floats == 0) tw = column_tile_width(csr.cols, c->col_tile_bytes);
+    if (used > 0 && (whole.lds_floats == 0 || spilling)) {
+        if (used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096)
+            tw = ((used + 1) / 2 + 63) & ~63;
+        else if (whole.lds_floats == 0) tw = column_tile_width(used, c->col_tile_bytes);
+        tbase = cmin & ~63;
     }
     if (tw > 0) {
-        m->col_tile_width = tw;
+        m->col_tile_width = tw; m->col_tile_base = tbase;
         m->parts.clear();
-        for (int32_t c0 = 0; c0 < csr.cols; c0 += tw) {
+        for (int64_t c0 = tbase; c0 <= cmax; c0 += tw) {
+            const bool first = c0 == tbase, last = c0 + tw > cmax;           // the end tiles are open-ended
+            Csr tile = column_tile(csr, first ? 0 : (int32_t)c0, last ? csr.cols : (int32_t)(c0 + tw));
             m->parts.emplace_back();
-            m->parts.back().st = build_stream(column_tile(csr, c0, std::min<int64_t>((int64_t)c0 + tw, csr.cols)));
+            m->parts.back().st = build_stream(tile);
             finish_part(m->parts.back(), c->n_cus);
         }
         // two tiles were meant to bring the x window into LDS: if they still gather through L2, tiling only
         // costs a launch and a read-modify-write of y -- go back to the single stream
-        bool lds_goal = csr.cols <= 2 * kMaxLdsFloats, all_lds = true;
+        bool lds_goal = used <= 2 * kMaxLdsFloats, all_lds = true;
         for (auto& p : m->parts)
             all_lds = all_lds && p.plan.lds_floats > 0 && p.plan.global_elems * 50 <= p.st.n_slices * (int64_t)kSliceElems;
-        if (lds_goal && !all_lds) {
+        if ((lds_goal && !all_lds) || m->parts.size() < 2) {
             m->parts.clear();
-            m->col_tile_width = 0;
+            m->col_tile_width = 0; m->col_tile_base = 0;
             m->parts.emplace_back();
             m->parts[0].st = build_stream(csr);
             finish_part(m->parts[0], c->n_cus);
@@ -781,7 +811,7 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->device_bytes = m.device_bytes; out->prep_seconds = m.prep_seconds;
     out->block_threads = m.plan_threads; out->group_slices = m.plan_group; out->lds_bytes = m.plan_lds * 4;
     out->col_tiles = (int32_t)m.parts.size();
-    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width;
+    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width; out->col_tile_base = m.col_tile_base; out->reserved = 0;
     return HISPMV_OK;
 }
 

@@ -146,6 +146,9 @@ typedef struct hispmv_matrix_info {
     int32_t col_tiles;      /* number of column tiles (1 = untiled) */
     int32_t carry_lookback; /* 1 = rows shared between slices are merged inside the launch (look-back), 0 = fix-up launch */
     int32_t col_tile_width; /* columns per tile when col_tiles > 1, else 0 */
+    int32_t col_tile_base;  /* tile t covers columns [base + t*width, base + (t+1)*width) of the range holding 99.8 % of the
+                               elements; the first tile also takes every column below, the last every column above */
+    int32_t reserved;
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);

@@ -31,10 +31,14 @@ def prepared_tiles(info, r, c, v, rows, cols):
     """The slice streams of the handle's column tiles, packed on the host the way the loader packs them."""
     from hispmv_amd.prep import prep_from_coo
     r, c, v = np.asarray(r), np.asarray(c), np.asarray(v, np.float32)
-    width = info["col_tile_width"] if info["col_tiles"] > 1 else cols
+    if info["col_tiles"] <= 1:
+        return [prep_from_coo(r, c, v, rows, cols)]
+    width, base, n = info["col_tile_width"], info["col_tile_base"], info["col_tiles"]
     tiles = []
-    for t in range(info["col_tiles"]):
-        sel = (c >= t * width) & (c < (t + 1) * width)
+    for t in range(n):                                     # the end tiles are open-ended (hispmv.h: col_tile_base)
+        lo = 0 if t == 0 else base + t * width
+        hi = cols if t == n - 1 else base + (t + 1) * width
+        sel = (c >= lo) & (c < hi)
         tiles.append(prep_from_coo(r[sel], c[sel], v[sel], rows, cols))
     return tiles
 
@@ -151,6 +155,21 @@ def test_column_tiled_scattered_matrix(fpga):
     y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
     assert bwd_err(y, y64, mag) < TOL
     assert np.array_equal(y.view(np.uint32), emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA).view(np.uint32))
+    # the same block inside a four times wider x (a rank's shard of a larger matrix, x replicated at full length):
+    # tiled over the columns it uses, not over the width of x -- still two tiles, none of them empty
+    off, wide = 2 * cols + 1000, 4 * cols
+    xw = rng.random(wide, dtype=np.float32)
+    c2 = c + off
+    c2[:40] = rng.integers(0, wide, 40)                     # a few strays anywhere (a shard's rows of the next block)
+    idx2 = fpga.create_sparse_handle(r, c2, v, rows, wide)
+    fpga.load_matrices()
+    info2 = fpga.matrix_info(idx2)
+    assert info2["col_tiles"] == 2 and abs(info2["col_tile_base"] - off) < 8192
+    fpga.select_matrix(idx2)
+    fpga.run_kernel(xw, b, y, ALPHA, BETA)
+    y64, mag = csr_truth(r, c2, v, rows, xw, b, ALPHA, BETA)
+    assert bwd_err(y, y64, mag) < TOL
+    assert np.array_equal(y.view(np.uint32), emulate_device(info2, r, c2, v, rows, wide, xw, b, ALPHA, BETA).view(np.uint32))
 
 
 def test_window_of_most_used_blocks_with_l2_spill(pyhispmv_mod, monkeypatch):
