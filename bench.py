@@ -285,14 +285,15 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b) * 1e-3)
             t = float(np.median(ts))
-            ab = M.algorithmic_bytes(m["rows"], m["cols"], m["nnz"])
+            ab = M.algorithmic_bytes(m["rows"], m["cols"] // world, m["nnz"])
             table.append(dict(name=m["name"], source=m["source"], rows=m["rows"], nnz=m["nnz"], us=round(t * 1e6, 2),
                               gflops=round(M.flops(m["rows"], m["nnz"]) / t / 1e9, 2), alg_gbs=round(ab / t / 1e9, 1),
                               pct_hbm_peak=round(100 * ab / t / 1e9 / HBM_PEAK_GBS, 2), slices=m["n_slices"],
                               split_rows=m["n_split"], prep_s=round(m["prep_seconds"], 3), plan=m["plan"]))
 
     flops_step = sum(M.flops(m["rows"], m["nnz"]) for m in mats)
-    bytes_step = sum(M.algorithmic_bytes(m["rows"], m["cols"], m["nnz"]) for m in mats)
+    # (x is replicated at full length on every rank, but a rank's block touches 1/world of it: count that part)
+    bytes_step = sum(M.algorithmic_bytes(m["rows"], m["cols"] // world, m["nnz"]) for m in mats)
     if rank == 0:
         total_flops = flops_step * world * args.steps
         total_bytes = bytes_step * world * args.steps
