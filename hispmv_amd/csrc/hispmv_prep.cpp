@@ -75,29 +75,59 @@ Coo read_mtx(const std::string& path, MtxFlavor flavor) {
 
     Coo out;
     out.rows = (int32_t)M; out.cols = (int32_t)N;
-    const size_t cap = (size_t)nz * ((mirror_sym || mirror_skew) ? 2 : 1);
-    out.r.reserve(cap); out.c.reserve(cap); out.v.reserve(cap);
-    const char* q = p;
-    for (long i = 0; i < nz && q < end; ++i) {
-        char* e1;
-        long r = std::strtol(q, &e1, 10);
-        if (e1 == q) break;
-        q = e1;
-        long c = std::strtol(q, &e1, 10);
-        if (e1 == q) break;
-        q = e1;
-        float v = 1.0f;
-        if (!pattern) { v = std::strtof(q, &e1); if (e1 == q) break; q = e1; }
-        while (q < end && *q != '\n') q++;   // ignore the rest of the line
-        uint32_t bits; std::memcpy(&bits, &v, 4);
-        const bool drop = (flavor == kFlavorCommon) ? (v == 0.0f) : (bits == 0u);
-        if (drop) continue;
-        if (r < 1 || c < 1 || r > M || c > N) throw std::runtime_error("Error: entry out of range in " + path);
-        out.r.push_back((int32_t)(r - 1)); out.c.push_back((int32_t)(c - 1)); out.v.push_back(v);
-        if (r != c) {
-            if (mirror_sym) { out.r.push_back((int32_t)(c - 1)); out.c.push_back((int32_t)(r - 1)); out.v.push_back(v); }
-            else if (mirror_skew) { out.r.push_back((int32_t)(c - 1)); out.c.push_back((int32_t)(r - 1)); out.v.push_back(-v); }
+    // Entry lines, parsed in parallel: the byte range is cut at line starts, every chunk runs the same loop (an entry =
+    // "row col [value]", the rest of the line ignored; entries before the size line's count only; the first malformed
+    // entry ends the matrix), and the chunks are concatenated in file order.
+    struct Chunk { const char* b; const char* e; std::vector<int32_t> r, c; std::vector<float> v; long iters = 0; bool stopped = false; std::string err; };
+    auto parse = [&](Chunk& k, long limit) {
+        const char* q = k.b;
+        k.r.clear(); k.c.clear(); k.v.clear(); k.iters = 0; k.stopped = false;
+        while (k.iters < limit && q < k.e) {
+            char* e1;
+            while (q < k.e && std::isspace((unsigned char)*q)) q++;      // blank lines do not count as entries
+            if (q >= k.e) break;
+            long r = std::strtol(q, &e1, 10);
+            if (e1 == q) { k.stopped = true; break; }
+            q = e1;
+            long c = std::strtol(q, &e1, 10);
+            if (e1 == q) { k.stopped = true; break; }
+            q = e1;
+            float v = 1.0f;
+            if (!pattern) { v = std::strtof(q, &e1); if (e1 == q) { k.stopped = true; break; } q = e1; }
+            while (q < end && *q != '\n') q++;   // ignore the rest of the line
+            k.iters++;
+            uint32_t bits; std::memcpy(&bits, &v, 4);
+            const bool drop = (flavor == kFlavorCommon) ? (v == 0.0f) : (bits == 0u);
+            if (drop) continue;
+            if (r < 1 || c < 1 || r > M || c > N) { k.err = "Error: entry out of range in " + path; k.stopped = true; break; }
+            k.r.push_back((int32_t)(r - 1)); k.c.push_back((int32_t)(c - 1)); k.v.push_back(v);
+            if (r != c) {
+                if (mirror_sym) { k.r.push_back((int32_t)(c - 1)); k.c.push_back((int32_t)(r - 1)); k.v.push_back(v); }
+                else if (mirror_skew) { k.r.push_back((int32_t)(c - 1)); k.c.push_back((int32_t)(r - 1)); k.v.push_back(-v); }
+            }
         }
+    };
+    long chunk_bytes = 4 << 20;
+    if (const char* env = std::getenv("HISPMV_MTX_CHUNK_BYTES")) chunk_bytes = std::max(16L, std::atol(env));
+    std::vector<Chunk> chunks;
+    for (const char* b = p; b < end;) {
+        const char* e = (end - b > chunk_bytes) ? b + chunk_bytes : end;
+        if (e < end) { const char* nl = (const char*)std::memchr(e, '\n', (size_t)(end - e)); e = nl ? nl + 1 : end; }
+        chunks.push_back(Chunk{b, e, {}, {}, {}});
+        b = e;
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long i = 0; i < (long)chunks.size(); ++i) parse(chunks[(size_t)i], nz);
+    long taken = 0;
+    for (Chunk& k : chunks) {
+        if (taken >= nz) break;
+        if (taken + k.iters > nz) parse(k, nz - taken);          // the file holds more lines than its size line says
+        if (!k.err.empty()) throw std::runtime_error(k.err);
+        out.r.insert(out.r.end(), k.r.begin(), k.r.end());
+        out.c.insert(out.c.end(), k.c.begin(), k.c.end());
+        out.v.insert(out.v.end(), k.v.begin(), k.v.end());
+        taken += k.iters;
+        if (k.stopped) break;
     }
     return out;
 }

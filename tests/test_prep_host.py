@@ -92,6 +92,25 @@ def test_product_reader_keeps_last_line_without_newline(tmp_path):
     assert prep_from_mtx(p, 0).nnz == 4054      # the reference loses it; we do not
 
 
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_parallel_reader_chunks_give_the_same_matrix(name, monkeypatch, tmp_path):
+    """The MatrixMarket reader parses the entry lines in chunks cut at line starts (4 MiB; OpenMP): with chunks of a few
+    lines each, with blank lines in the file and with more entry lines than the size line announces, the matrix is
+    the one the single-chunk parse gives."""
+    src = GOLDEN / f"{name}.mtx"
+    ref = [prep_from_mtx(src, flavor=f) for f in (0, 1)]
+    lines = src.read_text().split("\n")
+    k = next(i for i, ln in enumerate(lines) if ln and not ln.startswith("%")) + 1          # first entry line
+    noisy = tmp_path / "noisy.mtx"
+    noisy.write_text("\n".join(lines[:k + 3] + ["", "   "] + lines[k + 3:]) + "\n" + "\n".join(lines[k:k + 2]) + "\n")
+    monkeypatch.setenv("HISPMV_MTX_CHUNK_BYTES", "48")
+    for f in (0, 1):
+        for path in (src, noisy):
+            P = prep_from_mtx(path, flavor=f)
+            assert np.array_equal(P.row_ptr, ref[f].row_ptr) and np.array_equal(P.col_idx, ref[f].col_idx)
+            assert np.array_equal(P.values.view(np.uint32), ref[f].values.view(np.uint32))
+
+
 def test_reader_rejects_what_the_reference_rejects(tmp_path):
     bad = tmp_path / "bad.mtx"
     bad.write_text("%%NotMatrixMarket matrix coordinate real general\n1 1 1\n1 1 1.0\n")
