@@ -393,6 +393,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* env = std::getenv("HISPMV_PLAN_CUS")) { const int v = std::atoi(env); if (v > 0) c->n_cus = v; }   // experiments
     *out = c.release();
     return HISPMV_OK;
 }

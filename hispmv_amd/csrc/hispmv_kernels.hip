@@ -179,7 +179,14 @@ __device__ __forceinline__ void slices_body(
     // (8 x global_load_dwordx4 = the whole 8 KiB, plus its header), so the HBM latency of slice k+1 hides
     // behind the gathers, scans and stores of slice k.  The first request goes out BEFORE the x window is
     // staged: it depends on nothing but the slice id.
-    long long slice = first + wave;
+    // Each workgroup walks its group from a different starting slice (rotation by a multiple of its id): workgroups
+    // that all march through their groups from slice 0 at the same pace read addresses one group stride apart at
+    // every moment, and some strides alias in the HBM channel hash -- PFlow_742 with 145 slices per workgroup ran 72
+    // instead of 63 us (142, 146, 149, 152 and 155 slices did not).  Not with look-back: its chains want slice order.
+    const int n_here = (int)(last > first ? last - first : 0);
+    const int rot = (LOOKBACK || n_here == 0) ? 0 : (int)((unsigned long long)group * 29ull % (unsigned)n_here);
+    int k_slice = wave;                                         // position in the group's rotated order
+    long long slice = k_slice < n_here ? first + (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : last;
     uint4 w[kSliceSteps];
     int4 h = int4{0, 0, 0, 0};
     if (slice < last) {
@@ -304,7 +311,8 @@ __device__ __forceinline__ void slices_body(
             asm volatile("" ::: "memory");
         }
         const long long cur = slice;
-        slice += n_waves;
+        k_slice += n_waves;
+        slice = k_slice < n_here ? first + (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : last;
         if (slice < last) {
             const uint4* p = words + slice * (kSliceElems / 2) + lane;
 #pragma unroll
