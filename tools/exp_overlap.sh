@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment: do an HBM-bound and an L2-request-bound kernel overlap when the big one leaves half a CU free?
 O=gpurun_out/exp_overlap; mkdir -p $O
-B="--no-cpu-baseline --steps 20 --warmup 3 --per-matrix-reps 0"
+B="--launch streams --no-cpu-baseline --steps 20 --warmup 3 --per-matrix-reps 0"
 for M in "PFlow_742,soc-Pokec" "PFlow_742,soc-Pokec,mouse_gene,TSOPF_RS_b2383,Si41Ge41H72,crankseg_2,ASIC_680k,nxp1,analytics"; do
   for P in auto 3 1; do
     for S in 1 2 4; do

@@ -3,7 +3,7 @@
 set -u
 O=gpurun_out/exp_small; mkdir -p $O
 SM=ASIC_680k,nxp1,analytics,boyd2,language,crystk03,trans5,ford2,lowThrust_7,c-52,hangGlider_3,poli_large,thread,nd6k
-M="--matrices $SM --no-cpu-baseline --streams 1 --steps 20 --warmup 3 --per-matrix-reps 20"
+M="--matrices $SM --launch streams --no-cpu-baseline --streams 1 --steps 20 --warmup 3 --per-matrix-reps 20"
 python3 bench.py $M --details $O/auto.json > $O/auto.log 2>&1 && \
 HISPMV_CARRY=fixup python3 bench.py $M --details $O/fixup.json > $O/fixup.log 2>&1 && \
 HISPMV_CARRY=lookback python3 bench.py $M --details $O/lookback.json > $O/lookback.log 2>&1 && \
