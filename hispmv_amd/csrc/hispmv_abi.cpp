@@ -723,8 +723,11 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
         const Matrix& m = *c->mats[idx[i]];
         if (!m.loaded) return fail(c, HISPMV_ESTATE, "spmv_device_batch called before load_matrices");
         if (!d_x[i] || !d_y[i] || (beta != 0.0f && !d_bias[i])) return fail(c, HISPMV_EINVAL, "NULL device vector");
-        for (int k = 0; k < i; ++k)
+        for (int k = 0; k < i; ++k) {
             if (d_y[k] == d_y[i]) return fail(c, HISPMV_EINVAL, "two matrices of a batch write the same y");
+            // the carry buffers of cut rows belong to the handle: one SpMV per handle at a time (hispmv.h, threading)
+            if (idx[k] == idx[i] && !m.dense) return fail(c, HISPMV_EINVAL, "the same sparse handle twice in one batch");
+        }
         if (!m.dense) rounds = std::max(rounds, m.parts.size());
     }
     HIP_TRY(c, hipSetDevice(c->device));

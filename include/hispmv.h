@@ -107,7 +107,8 @@ float hispmv_last_kernel_ms(hispmv_ctx* ctx);
  * workgroups of all matrices with the same workgroup size share ONE grid (plus one fix-up launch), so small matrices no
  * longer pay 6-20 us of launch latency each (no reference counterpart: the reference runs one matrix at a time,
  * fpga_handle.cpp:286-321).  idx, d_x, d_bias, d_y are HOST arrays of n entries (device pointers inside); the y_i must
- * be distinct.  Rows cut by slice boundaries always take the fix-up variant here, so a result may differ in the last
+ * be distinct and a sparse handle may appear only once (its carry buffers belong to the handle).  Rows cut by slice
+ * boundaries always take the fix-up variant here, so a result may differ in the last
  * bit from hispmv_spmv_device on a matrix whose single launch uses the look-back variant.  Asynchronous on `stream`. */
 int hispmv_spmv_device_batch(hispmv_ctx* ctx, int32_t n, const int32_t* idx, const float* const* d_x,
                              const float* const* d_bias, float* const* d_y, float alpha, float beta, void* stream);

@@ -376,6 +376,13 @@ def test_multi_matrix_launch_matches_each_matrix_alone(fpga):
             fpga.select_matrix(i_dense)
             fpga.run_kernel(xd, bd, yd, alpha, beta)
             assert np.array_equal(dyd.cpu().numpy(), yd)
+    m0, m1 = mats[0], mats[1]
+    with pytest.raises(ValueError):          # one SpMV per sparse handle at a time: its carry buffers are shared
+        fpga.spmv_device_batch(fpga.prepare_batch([m0["idx"], m0["idx"]], [m0["dx"].data_ptr()] * 2, [m0["db"].data_ptr()] * 2,
+                                                  [m0["dy"].data_ptr(), m1["dy"].data_ptr()]), 1.0, 1.0)
+    with pytest.raises(ValueError):          # two results in the same place
+        fpga.spmv_device_batch(fpga.prepare_batch([m0["idx"], m1["idx"]], [m0["dx"].data_ptr(), m1["dx"].data_ptr()],
+                                                  [m0["db"].data_ptr(), m1["db"].data_ptr()], [m0["dy"].data_ptr()] * 2), 1.0, 1.0)
 
 
 @pytest.mark.parametrize("alpha,beta", [(ALPHA_HOST, BETA_HOST), (1.0, 0.0), (0.0, 1.0), (-1.5, 0.5)])
