@@ -40,6 +40,20 @@ def test_create_argument_errors_mirror_the_reference():
     assert not ctx.value
 
 
+def test_device_entry_points_check_their_arguments_before_touching_the_device():
+    """Argument errors of the device-pointer entry points come back as HISPMV_EINVAL without a launch (so they can be
+    checked on a CPU-only box): NULL context, negative counts, missing tables."""
+    from hispmv_amd import _lib
+    lib = _lib.lib
+    assert lib.hispmv_spmv_device_batch(None, 0, None, None, None, None, 1.0, 1.0, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_spmv_device(None, 0, None, None, None, 1.0, 1.0, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_boundary_pack(None, None, None, -1, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_boundary_pack(None, None, None, 3, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_boundary_apply(None, None, None, 3, 2, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_boundary_apply(None, None, None, 0, 0, None) == _lib.HISPMV_EINVAL      # world < 1
+    assert lib.hispmv_synchronize(None) == _lib.HISPMV_EINVAL
+
+
 def test_facade_fails_loudly_without_a_device():
     import os
     if os.path.exists("/dev/kfd"):
