@@ -1,0 +1,46 @@
+// Sanitizer driver for the host side (tools/sanitize_host.sh): random matrices of five kinds through
+// coo_to_csr -> build_stream -> make_plan, and the MatrixMarket reader on the files given as arguments.
+#include <cstdio>
+#include <random>
+
+#include "hispmv_plan.h"
+#include "hispmv_prep.h"
+using namespace hispmv;
+
+int main(int argc, char** argv) {
+    for (int i = 1; i < argc; ++i)
+        for (int fl = 0; fl < 2; ++fl) {
+            try { Coo c = read_mtx(argv[i], (MtxFlavor)fl); std::printf("%s flavor %d: %d x %d, %zu entries\n", argv[i], fl, c.rows, c.cols, c.r.size()); }
+            catch (const std::exception& e) { std::printf("%s flavor %d: %s\n", argv[i], fl, e.what()); }
+        }
+    std::mt19937 g(5);
+    for (int t = 0; t < 60; ++t) {
+        const int rows = 1 + g() % 60000, cols = 1 + g() % 90000, kind = t % 5;
+        const long nnz = g() % 400000;
+        std::vector<int32_t> r(nnz), c(nnz);
+        std::vector<float> v(nnz);
+        for (long i = 0; i < nnz; ++i) {
+            r[i] = g() % rows;
+            if (kind == 1 && i < nnz / 3) r[i] = rows / 2;                       // one heavy row
+            if (kind == 2) r[i] = (r[i] / 3) * 3 % rows;                         // empty rows
+            c[i] = kind == 3 ? (int)(((long)r[i] * cols / rows + g() % 200) % cols) : g() % cols;
+            if (kind == 4) c[i] = (int)(((long)r[i] * cols / rows + (g() % 16 ? g() % 100 : g() % cols)) % cols);   // band + strays
+            v[i] = (float)(g() % 100) / 50.f - 1.f;
+        }
+        Csr m = coo_to_csr(rows, cols, nnz, r.data(), c.data(), v.data());
+        SliceStream st = build_stream(m);
+        for (int cus : {256, 8, 1}) { SliceStream copy = st; LaunchPlan p = make_plan(copy, cus); (void)p; }
+    }
+    {   // a stencil matrix large enough for LDS-window plans
+        const int rows = 300000, per = 40;
+        std::vector<int32_t> r, c;
+        std::vector<float> v;
+        for (int i = 0; i < rows; ++i)
+            for (int k = 0; k < per; ++k) { r.push_back(i); c.push_back((i + (k * 37) % 3000) % rows); v.push_back(1.f); }
+        Csr m = coo_to_csr(rows, rows, (long)r.size(), r.data(), c.data(), v.data());
+        SliceStream st = build_stream(m);
+        LaunchPlan p = make_plan(st, 256);
+        std::printf("stencil: slices %lld, %d threads, %d slices per workgroup, window %d floats\n", (long long)st.n_slices, p.block_threads, p.group_slices, p.lds_floats);
+    }
+    std::puts("sanitize_host: done");
+}
