@@ -113,6 +113,15 @@ def cpu_baseline(mats, budget_s=20.0):
                 r = oracle.mkl_spmv(m["rp"], m["ci"], m["va"], cols, x, y0, 0.85, 0.0, reps_m, cores)
                 res["mkl"][0] += fl * reps_m; res["mkl"][1] += r[0] * reps_m; used["mkl"] = r[1]
         sample.append(m["name"])
+    # the reference's own single-thread loop (cpu_spmv, cpu/src/main.cpp:11-23) on the three largest matrices, one pass each
+    one_fl = one_t = 0.0
+    for m in sorted((q for q in mats if "rp" in q), key=lambda q: -q["nnz"])[:3]:
+        x = ((np.arange(m["cols"], dtype=np.float32) + 1) / (np.arange(m["cols"], dtype=np.float32) + 2)).astype(np.float32)
+        y0 = np.zeros(m["rows"], np.float32)
+        t0 = time.perf_counter()
+        oracle.cpu_spmv(m["rp"], m["ci"], m["va"], x, y0, 0.85, -2.06, 1)
+        one_t += time.perf_counter() - t0
+        one_fl += 2.0 * (m["nnz"] + m["rows"])
     omp = res["omp"][0] / res["omp"][1] / 1e9 if res["omp"][1] > 0 else None
     mkl = res["mkl"][0] / res["mkl"][1] / 1e9 if res["mkl"][1] > 0 else None
     primary = "mkl_sparse_s_mv" if mkl is not None else "openmp_csr"
@@ -121,6 +130,7 @@ def cpu_baseline(mats, budget_s=20.0):
         "cores": used["mkl"] if mkl is not None else used["omp"], "kind": "port", "impl": primary,
         "openmp_csr_gflops": None if omp is None else round(omp, 3),
         "mkl_gflops": None if mkl is None else round(mkl, 3),
+        "cpu_spmv_1_thread_gflops": round(one_fl / one_t / 1e9, 3) if one_t > 0 else None,
         "sample": f"{len(sample)} matrices of the same set ({', '.join(sample[:3])}...), reps bounded to ~{budget_s:.0f} s total "
                   f"(reference: 200 reps each, cpu/run_spmv.sh:6), alpha=0.85 beta=-2.06 as cpu/src/main.cpp:147-148",
     }
