@@ -109,8 +109,13 @@ int main(int argc, char** argv) {
     std::mt19937_64 g(1);
     // pattern: 0 = uniform random in table; 1 = window-local: each 4096-element group draws from a 16 KiB window
     // sliding through the table; 2 = runs of 4 consecutive columns, uniform run starts
-    const long long tables[] = {16 << 10, 128 << 10, 1 << 20, 8ll << 20, 64ll << 20};
-    for (int pattern = 0; pattern < 3; ++pattern) {
+    std::vector<long long> tables = {16 << 10, 128 << 10, 1 << 20, 8ll << 20, 64ll << 20};
+    int n_patterns = 3;
+    if (argc > 1) {               // ./gather_bench <bytes>[,<bytes>...]: uniform pattern only, these table sizes
+        tables.clear(); n_patterns = 1;
+        for (char* tok = strtok(argv[1], ","); tok; tok = strtok(nullptr, ",")) tables.push_back(atoll(tok));
+    }
+    for (int pattern = 0; pattern < n_patterns; ++pattern) {
         for (long long table : tables) {
             const long long nf = table / 4;
             for (long long i = 0; i < n_elems; ++i) {
