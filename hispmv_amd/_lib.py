@@ -44,6 +44,7 @@ _f32p = C.POINTER(C.c_float)
 # name -> (restype, argtypes); every symbol include/hispmv.h declares.
 SIGNATURES = {
     "hispmv_version": (C.c_char_p, []),
+    "hispmv_free_failures": (C.c_int64, []),
     "hispmv_boundary_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "hispmv_boundary_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hispmv_create": (C.c_int, [C.POINTER(_p), C.c_char_p] + [C.c_int] * 9),

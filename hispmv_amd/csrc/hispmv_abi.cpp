@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,7 @@ struct hispmv_ctx {
     int num_ch_A = 0, num_ch_B = 0, num_ch_C = 0, urams_per_pe = 0, fp_acc_latency = 0;
     bool dense_overlay = false, pre_accumulator = false, row_dist_net = false;
     hipStream_t stream = nullptr;
+    hipStream_t user_stream = nullptr;   // last caller-supplied stream a launch went to (hispmv_synchronize waits for it too)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.0f;
     std::mutex mu;
@@ -116,6 +118,18 @@ int hip_fail(hispmv_ctx* c, hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail((c), e_, #call);  \
     } while (0)
 
+// Every device / pinned allocation of the library is released through these: a failing free (a pointer freed twice, a
+// pointer the runtime does not know) is counted, and hispmv_free_failures() lets a test read the count.
+std::atomic<int64_t> g_free_failures{0};
+template <class T> void dev_free(T*& p) {
+    if (p && hipFree((void*)p) != hipSuccess) { g_free_failures++; (void)hipGetLastError(); }
+    p = nullptr;
+}
+template <class T> void host_free(T*& p) {
+    if (p && hipHostFree((void*)p) != hipSuccess) { g_free_failures++; (void)hipGetLastError(); }
+    p = nullptr;
+}
+
 int64_t sparse_device_bytes(const SliceStream& st) {
     return (int64_t)st.words.size() * 8 + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
            (int64_t)st.n_slices * 12 + 8;
@@ -133,7 +147,7 @@ int check_device_error(hispmv_ctx* c) {
 }
 
 void free_matrix_device(Matrix& m) {
-    for (void* p : m.allocs) (void)hipFree(p);
+    for (void*& p : m.allocs) dev_free(p);
     m.allocs.clear();
     for (auto& p : m.parts) p.dev = SpmvDeviceMatrix{};
     m.d_dense = nullptr;
@@ -142,8 +156,8 @@ void free_matrix_device(Matrix& m) {
 
 int ensure_vec(hispmv_ctx* c, float** p, int64_t* cap, int64_t n) {
     if (n <= *cap) return HISPMV_OK;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr; *cap = 0;
+    dev_free(*p);
+    *cap = 0;
     const int64_t want = std::max<int64_t>(n, 1024);
     HIP_TRY(c, hipMalloc((void**)p, (size_t)want * sizeof(float)));
     *cap = want;
@@ -352,9 +366,13 @@ HISPMV_API int hispmv_boundary_apply(float* const* d_first, const float* d_recv,
     return launch_boundary_apply(d_first, d_recv, d_weights, n, world, (hipStream_t)stream) == hipSuccess ? HISPMV_OK : HISPMV_EDEVICE;
 }
 
-HISPMV_API const char* hispmv_version(void) { return "hispmv-amd 0.1.0 gfx950"; }
+HISPMV_API const char* hispmv_version(void) { return "hispmv-amd 0.2.0 gfx950"; }
+
+HISPMV_API int64_t hispmv_free_failures(void) { return g_free_failures.load(); }
 
 HISPMV_API const char* hispmv_last_error(const hispmv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+HISPMV_API void hispmv_destroy(hispmv_ctx* c);
 
 HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int device_id, int a, int b, int cc,
                              int urams, int fp_acc_latency, int dense, int pre_acc, int row_dist) {
@@ -384,11 +402,13 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     c->dense_overlay = dense != 0; c->pre_accumulator = pre_acc != 0; c->row_dist_net = row_dist != 0;
     c->arena_budget = (int64_t)a * 256 * 1024 * 1024;      // fpga_handle.h:12, one 256 MiB bank per A channel
     if (const char* env = std::getenv("HISPMV_ARENA_BYTES")) { long long v = std::atoll(env); if (v > 0) c->arena_budget = v; }
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(nullptr, e, "hipStreamCreate");
-    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return hip_fail(nullptr, e, "hipEventCreate");
-    if ((e = hipHostMalloc((void**)&c->h_err, sizeof(int), hipHostMallocMapped)) != hipSuccess) return hip_fail(nullptr, e, "hipHostMalloc(err flag)");
+    // from here on the context owns HIP objects: a failure releases them through hispmv_destroy
+    auto give_up = [&](hipError_t err, const char* what) { hispmv_destroy(c.release()); return hip_fail(nullptr, err, what); };
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return give_up(e, "hipEventCreate");
+    if ((e = hipHostMalloc((void**)&c->h_err, sizeof(int), hipHostMallocMapped)) != hipSuccess) return give_up(e, "hipHostMalloc(err flag)");
     *c->h_err = 0;
-    if ((e = hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0)) != hipSuccess) return hip_fail(nullptr, e, "hipHostGetDevicePointer(err flag)");
+    if ((e = hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0)) != hipSuccess) return give_up(e, "hipHostGetDevicePointer(err flag)");
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
@@ -403,11 +423,12 @@ HISPMV_API void hispmv_destroy(hispmv_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& m : c->mats) free_matrix_device(*m);
-    if (c->d_x) (void)hipFree(c->d_x);
-    if (c->d_y) (void)hipFree(c->d_y);
-    if (c->h_err) (void)hipHostFree(c->h_err);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (auto& t : c->multi_tables) { if (t.d_entries) (void)hipFree(t.d_entries); if (t.d_fix) (void)hipFree(t.d_fix); }
+    dev_free(c->d_x);
+    dev_free(c->d_y);
+    host_free(c->h_err);
+    host_free(c->h_stage);
+    for (auto& t : c->multi_tables) { dev_free(t.d_entries); dev_free(t.d_fix); }
+    c->multi_tables.clear();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -469,8 +490,10 @@ HISPMV_API int hispmv_create_sparse_handle_from_csr(hispmv_ctx* c, const int32_t
         const int64_t nnz = rp[rows];
         if (rp[0] != 0 || nnz < 0) return fail(c, HISPMV_EINVAL, "row_ptr must start at 0");
         for (int32_t i = 0; i < rows; ++i) if (rp[i + 1] < rp[i]) return fail(c, HISPMV_EINVAL, "row_ptr must be non-decreasing");
+        if (nnz > 0 && (!ci || !va)) return fail(c, HISPMV_EINVAL, "col_idx / values are NULL");
         csr.col.assign(ci, ci + nnz); csr.val.assign(va, va + nnz);
         for (int64_t k = 0; k < nnz; ++k) if (ci[k] < 0 || ci[k] >= cols) return fail(c, HISPMV_EINVAL, "CSR column outside matrix");
+        sort_rows_by_column(csr);     // rows with unsorted columns (scipy: has_sorted_indices == False) are sorted, stably
         double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return add_sparse(c, std::move(csr), t);
     } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory");
@@ -605,9 +628,8 @@ static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t nu
     const bool staged = (nx + nb + ny) * (int64_t)sizeof(float) <= (8 << 20);     // small vectors: through pinned memory
     if (staged) {
         if (nx + nb + ny > c->cap_stage) {
-            if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (auto& t : c->multi_tables) { if (t.d_entries) (void)hipFree(t.d_entries); if (t.d_fix) (void)hipFree(t.d_fix); }
-            c->h_stage = nullptr; c->cap_stage = 0;
+            host_free(c->h_stage);      // (the staging block only; the batch tables are not touched by this path)
+            c->cap_stage = 0;
             const int64_t want = std::max<int64_t>(nx + nb + ny, 1 << 16);
             HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, (size_t)want * sizeof(float), hipHostMallocDefault));
             c->cap_stage = want;
@@ -661,6 +683,7 @@ HISPMV_API int hispmv_spmv_device(hispmv_ctx* c, int idx, const float* d_x, cons
     if (!m.loaded) return fail(c, HISPMV_ESTATE, "spmv_device called before load_matrices");
     if (!d_x || !d_y || (beta != 0.0f && !d_bias)) return fail(c, HISPMV_EINVAL, "NULL device vector");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (stream) c->user_stream = (hipStream_t)stream;
     return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, stream ? (hipStream_t)stream : c->stream);
 }
 
@@ -678,7 +701,7 @@ static int launch_multi_class(hispmv_ctx* c, const std::vector<int>& sel, int r,
     for (auto& t : c->multi_tables) if (t.key == key) { tab = &t; break; }
     if (!tab) {
         if (c->multi_tables.size() >= 64) {      // callers that keep changing their vectors: start over
-            for (auto& t : c->multi_tables) { if (t.d_entries) (void)hipFree(t.d_entries); if (t.d_fix) (void)hipFree(t.d_fix); }
+            for (auto& t : c->multi_tables) { dev_free(t.d_entries); dev_free(t.d_fix); }
             c->multi_tables.clear();
         }
         hispmv_ctx::MultiTable t;
@@ -732,6 +755,7 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
     }
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (stream) c->user_stream = (hipStream_t)stream;
     const float* const* bias = d_bias;
     std::vector<const float*> no_bias;
     if (!bias) { no_bias.assign((size_t)n, nullptr); bias = no_bias.data(); }
@@ -783,6 +807,13 @@ HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
     if (!c) return HISPMV_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->user_stream) {
+        const hipError_t e = hipStreamSynchronize(c->user_stream);
+        if (e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed) {
+            (void)hipGetLastError();          // the caller has destroyed that stream since: nothing left to wait for
+            c->user_stream = nullptr;
+        } else if (e != hipSuccess) return hip_fail(c, e, "hipStreamSynchronize(caller stream)");
+    }
     return check_device_error(c);
 }
 

@@ -135,6 +135,29 @@ Coo read_mtx(const std::string& path, MtxFlavor flavor) {
 // ---------------------------------------------------------------------------
 // COO -> CSR
 // ---------------------------------------------------------------------------
+// Stable sort by column inside each row (rows already ascending are skipped): everything downstream (column windows
+// of a slice, column tiles) takes a row's first / last column from its ends.
+void sort_rows_by_column(Csr& m) {
+    const int32_t rows = m.rows;
+#pragma omp parallel
+    {
+        std::vector<std::pair<int32_t, float>> tmp;
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t i = 0; i < rows; ++i) {
+            const int64_t s = m.row_ptr[i], e = m.row_ptr[(size_t)i + 1];
+            if (e - s < 2) continue;
+            bool sorted = true;
+            for (int64_t k = s + 1; k < e; ++k) if (m.col[k] < m.col[k - 1]) { sorted = false; break; }
+            if (sorted) continue;
+            tmp.resize((size_t)(e - s));
+            for (int64_t k = s; k < e; ++k) tmp[k - s] = {m.col[k], m.val[k]};
+            std::stable_sort(tmp.begin(), tmp.end(),
+                             [](const std::pair<int32_t, float>& a, const std::pair<int32_t, float>& b) { return a.first < b.first; });
+            for (int64_t k = s; k < e; ++k) { m.col[k] = tmp[k - s].first; m.val[k] = tmp[k - s].second; }
+        }
+    }
+}
+
 Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const int32_t* c, const float* v) {
     if (rows < 0 || cols < 0 || nnz < 0) throw std::out_of_range("negative dimension");
     // the kernels address x, bias and y with 32-bit byte offsets (buffer descriptors)
@@ -191,24 +214,7 @@ Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const 
             }
         }
     }
-    // stable sort by column inside each row (rows already ascending are skipped)
-#pragma omp parallel
-    {
-        std::vector<std::pair<int32_t, float>> tmp;
-#pragma omp for schedule(dynamic, 256)
-        for (int32_t i = 0; i < rows; ++i) {
-            const int64_t s = m.row_ptr[i], e = m.row_ptr[(size_t)i + 1];
-            if (e - s < 2) continue;
-            bool sorted = true;
-            for (int64_t k = s + 1; k < e; ++k) if (m.col[k] < m.col[k - 1]) { sorted = false; break; }
-            if (sorted) continue;
-            tmp.resize((size_t)(e - s));
-            for (int64_t k = s; k < e; ++k) tmp[k - s] = {m.col[k], m.val[k]};
-            std::stable_sort(tmp.begin(), tmp.end(),
-                             [](const std::pair<int32_t, float>& a, const std::pair<int32_t, float>& b) { return a.first < b.first; });
-            for (int64_t k = s; k < e; ++k) { m.col[k] = tmp[k - s].first; m.val[k] = tmp[k - s].second; }
-        }
-    }
+    sort_rows_by_column(m);
     return m;
 }
 

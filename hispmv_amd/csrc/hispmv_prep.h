@@ -76,6 +76,9 @@ Coo read_mtx(const std::string& path, MtxFlavor flavor);
 // them too).  Throws std::out_of_range on an index outside [0,rows) x [0,cols).
 Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const int32_t* c, const float* v);
 
+// Stable per-row sort by column of a CSR whose rows may be unsorted (rows already ascending are left alone).
+void sort_rows_by_column(Csr& m);
+
 // CSR -> slice stream.
 SliceStream build_stream(const Csr& m);
 

@@ -211,6 +211,111 @@ def rmat_coo(scale: int, edge_factor: int = 16, a=0.57, b=0.19, c=0.19, seed: in
     return n, n, r.astype(np.int32), cc.astype(np.int32), v
 
 
+def _columns_for_rows(rng, lens: np.ndarray, cols: int) -> np.ndarray:
+    """Ascending columns for rows of the given lengths: one uniform draw in each of len equal strata of
+    [0, cols) (rows longer than cols repeat columns: duplicates are legal, spmv-helper.cpp keeps them)."""
+    nnz = int(lens.sum())
+    row_ptr = np.zeros(lens.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=row_ptr[1:])
+    row_of = np.repeat(np.arange(lens.size, dtype=np.int32), lens)
+    k = np.arange(nnz, dtype=np.int64) - row_ptr[:-1][row_of]
+    stratum = (cols / np.maximum(lens, 1))[row_of]
+    col = np.floor((k + rng.random(nnz)) * stratum).astype(np.int64)
+    return np.minimum(col, cols - 1).astype(np.int32)
+
+
+def _finish_csr(rng, lens: np.ndarray, cols: int):
+    lens = lens.astype(np.int64)
+    rp = np.zeros(lens.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=rp[1:])
+    assert rp[-1] < 2**31
+    col = _columns_for_rows(rng, lens, cols)
+    val = rng.random(int(rp[-1]), dtype=np.float32) * np.float32(2.0) - np.float32(1.0)
+    val[val == 0] = np.float32(0.5)
+    return rp.astype(np.int32), col, val
+
+
+def zipf_csr(rows: int, cols: int, nnz: int, s: float = 1.2, seed: int = 7):
+    """Zipf(s) row lengths (rank k of a random row order gets ~ k^-s of the entries, capped
+    at `cols`) x uniform columns.  At soc-Pokec's shape (1 632 803^2, 30.6 M) the top rows are full."""
+    rng = np.random.default_rng(seed)
+    w = 1.0 / (rng.permutation(rows) + 1.0) ** s
+    scale = nnz / w.sum()
+    for _ in range(40):                       # the cap takes entries away from the top ranks: rescale the rest
+        lam = np.minimum(w * scale, cols)
+        scale *= nnz / lam.sum()
+    lens = np.floor(np.minimum(w * scale, cols)).astype(np.int64)
+    short = int(nnz - lens.sum())
+    if short > 0:
+        np.add.at(lens, rng.integers(0, rows, size=short), 1)
+    elif short < 0:
+        cand = np.nonzero(lens > 0)[0]
+        lens[rng.choice(cand, size=-short, replace=False)] -= 1
+    return _finish_csr(rng, lens, cols)
+
+
+def heavy_rows_csr(rows: int, cols: int, nnz: int, heavy_share: float = 0.9, heavy_rows: float = 0.01, seed: int = 11):
+    """SURVEY.md 8(d) C3 adversarial: `heavy_rows` of the rows (chosen at random) hold `heavy_share` of the entries."""
+    rng = np.random.default_rng(seed)
+    nh = max(1, int(rows * heavy_rows))
+    heavy = rng.choice(rows, size=nh, replace=False)
+    lens = np.zeros(rows, dtype=np.int64)
+    n_heavy = int(nnz * heavy_share)
+    lens[heavy] = n_heavy // nh
+    lens[heavy[: n_heavy - (n_heavy // nh) * nh]] += 1
+    np.add.at(lens, rng.integers(0, rows, size=nnz - n_heavy), 1)
+    return _finish_csr(rng, np.minimum(lens, 4 * cols), cols)
+
+
+def full_row_plus_diagonal(n: int, row: int = 17, seed: int = 13):
+    """SURVEY.md 8(d) C3 adversarial: the diagonal plus one full row (nnz of that row = cols)."""
+    rng = np.random.default_rng(seed)
+    lens = np.ones(n, dtype=np.int64)
+    lens[row] = n
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=rp[1:])
+    col = np.empty(int(rp[-1]), dtype=np.int32)
+    diag = np.arange(n, dtype=np.int32)
+    col[rp[:-1]] = diag
+    col[rp[row]:rp[row + 1]] = diag
+    val = rng.random(col.size, dtype=np.float32) * np.float32(2.0) - np.float32(1.0)
+    val[val == 0] = np.float32(0.5)
+    return rp.astype(np.int32), col, val
+
+
+def model_test_layers(seed: int = 0):
+    """SURVEY.md 8(d) C4 (apps/model_test.py:22-29, model.py:58-77 defaults): W1 dense 8192x4096, W2 sparse 8192x8192
+    density 0.1, W3 sparse 1024x8192 density 0.25, with biases.  -> list of (kind, W or (r, c, v), rows, cols, bias)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    W1 = (rng.random((8192, 4096), dtype=np.float32) - np.float32(0.5)) * np.float32(0.05)
+    out.append(("dense", W1, 8192, 4096, rng.random(8192, dtype=np.float32)))
+    for rows, cols, dens in ((8192, 8192, 0.1), (1024, 8192, 0.25)):
+        mask = rng.random((rows, cols), dtype=np.float32) < dens
+        r, c = np.nonzero(mask)
+        v = (rng.random(r.size, dtype=np.float32) - np.float32(0.5)) * np.float32(0.05)
+        v[v == 0] = np.float32(0.01)
+        out.append(("sparse", (r.astype(np.int32), c.astype(np.int32), v), rows, cols, rng.random(rows, dtype=np.float32)))
+    return out
+
+
+def benchmark_set(names=None, uniform: bool = False, seed_shift: int = 0):
+    """The matrices of a bench step (BASELINE.json configs[1]), exactly as bench.py and the parity tests build them:
+    a real file under matrices/<name>/ when present, else the seeded stand-in.  -> list of dicts with
+    name, source and either path or rows/cols/nnz/rp/ci/va."""
+    out = []
+    for name, rows, nnz, fam, par in SUITESPARSE_SET:
+        if names and name not in names:
+            continue
+        real = real_matrix_path(name)
+        if real is not None and seed_shift == 0:
+            out.append(dict(name=name, source="file:" + str(real), path=str(real)))
+            continue
+        rp, ci, va, used = make_standin(name, rows, nnz, fam, par, zlib.crc32(name.encode()) + seed_shift, uniform)
+        out.append(dict(name=name, source=f"synthetic:{used}", family=fam, rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
+    return out
+
+
 def write_mtx(path, rows: int, cols: int, r, c, v, symmetry: str = "general", comment: str = "hispmv_amd") -> None:
     with open(path, "w") as f:
         f.write(f"%%MatrixMarket matrix coordinate real {symmetry}\n% {comment}\n{rows} {cols} {len(r)}\n")

@@ -65,7 +65,9 @@ int hispmv_create_sparse_handle(hispmv_ctx* ctx, const int32_t* coo_rows, const 
  * semantics (cpu/src/helper_functions.cpp:91-146). */
 int hispmv_create_sparse_handle_from_mtx(hispmv_ctx* ctx, const char* mtx_path, int flavor);
 
-/* CSR input (what cpu/src/main.cpp:26-33 hands MKL): row_ptr[rows+1], columns ascending per row. */
+/* CSR input (what cpu/src/main.cpp:26-33 hands MKL): row_ptr[rows+1] starting at 0 and non-decreasing, columns inside
+ * [0, cols).  Rows whose columns are not ascending (scipy: has_sorted_indices == False) are sorted by column on the
+ * way in (stably: duplicates keep their order); NULL col_idx / values with nnz > 0 -> HISPMV_EINVAL. */
 int hispmv_create_sparse_handle_from_csr(hispmv_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx,
                                          const float* values, int32_t rows, int32_t cols);
 
@@ -97,6 +99,9 @@ int hispmv_linear(hispmv_ctx* ctx, int matrix_idx, const float* x, int64_t x_len
  * `stream` (a hipStream_t, NULL = the context's stream).  Used by bench.py and the multi-GPU driver. */
 int hispmv_spmv_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, const float* d_bias, float* d_y,
                        float alpha, float beta, void* stream);
+/* Waits for the context's stream and for the last caller-supplied stream a launch of this context went to, then reports
+ * a device-side error of those launches (HISPMV_EDEVICE: an in-kernel bounded wait expired).  Launches sent to OTHER
+ * caller streams before that must be synchronised by the caller first. */
 int hispmv_synchronize(hispmv_ctx* ctx);
 
 /* Whole-kernel device time of the last hispmv_spmv_device/run_kernel/linear launch sequence,
@@ -184,6 +189,10 @@ int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
 int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[2]);
 const int32_t* hispmv_prep_groups(const hispmv_prep* p);
 const int32_t* hispmv_prep_frags(const hispmv_prep* p);
+
+/* Number of device / pinned-memory frees the runtime rejected since the library was loaded (a pointer released twice
+ * or never allocated); 0 in a correct run.  For tests. */
+int64_t hispmv_free_failures(void);
 
 /* Library identification: "hispmv-amd <version> gfx950". */
 const char* hispmv_version(void);

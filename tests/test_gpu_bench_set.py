@@ -1,0 +1,200 @@
+"""The benchmark workloads themselves under parity: every matrix bench.py times is built here the
+way bench.py builds it (hispmv_amd.matrices.benchmark_set: both stand-in families), run through the C ABI on the MI355X
+-- once in ONE hispmv_spmv_device_batch call (the bench's step) and once launched alone -- and each y is compared with
+
+  * the fp64 accumulation of the oracle (backward-error form of the 1e-5 gate, SURVEY.md section 7 hard part 1),
+  * the plain relative error |y - y64| / |y64| on rows without cancellation (mag / |y64| < 4): gate 1e-5 -- the literal
+    reading of BASELINE.json north_star -- and reported (not gated) over all rows,
+  * a live mkl_sparse_s_mv called as cpu/src/main.cpp:26-49 calls it, when the box has libmkl_rt.
+
+Also here: SURVEY.md 8(d) C3 (R-MAT scale 20, Zipf s=1.2 at soc-Pokec's shape, 1 % of the rows holding 90 % of the
+entries, one full row + diagonal) and the full-size C4 shapes of apps/model_test.py through `linear`, batch 1 and 8.
+Vectors and scalars: cpu/src/main.cpp:147-148,173-178."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ALPHA, BETA, TOL, ref_vectors
+
+pytestmark = pytest.mark.gpu
+
+HW = ("tests.xclbin", 0, 24, 1, 1, 2, 5, True, False, True)   # apps/general_test.py:10-19
+REPORT = []
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def check_y(name, y, rp, ci, va, cols, x, b, alpha, beta, mkl=True):
+    """All gates for one result vector; returns the figures for the report."""
+    y64, mag = oracle.spmv_f64(rp, ci, va, x, b, alpha, beta)
+    mag = np.maximum(mag, np.finfo(np.float64).tiny)
+    err = np.abs(y.astype(np.float64) - y64)
+    bwd = float(np.max(err / mag))
+    assert np.all(np.isfinite(y)), f"{name}: non-finite y"
+    assert bwd < TOL, f"{name}: backward error {bwd:.3e}"
+    nz = np.abs(y64) > 0
+    rel = np.zeros_like(err)
+    rel[nz] = err[nz] / np.abs(y64[nz])
+    well = nz & (mag < 4 * np.abs(y64))                     # rows whose terms do not cancel
+    rel_well = float(rel[well].max()) if well.any() else 0.0
+    assert rel_well < TOL, f"{name}: plain relative error {rel_well:.3e} on a row without cancellation"
+    out = dict(name=name, rows=int(y.size), nnz=int(rp[-1]), bwd=bwd, rel_well=rel_well, rel_all=float(rel.max()),
+               well_rows=int(well.sum()))
+    if mkl and oracle.mkl_available():
+        r = oracle.mkl_spmv(rp, ci, va, cols, x, b, alpha, beta, 1, 0)
+        if r is not None:
+            d = float(np.max(np.abs(y.astype(np.float64) - r[2].astype(np.float64)) / mag))
+            assert d < 2 * TOL, f"{name}: differs from mkl_sparse_s_mv by {d:.3e} (backward scale)"
+            pl, _, _ = oracle.precision_loss(r[2], y)      # the reference's own metric, cpu/src/main.cpp:99-132
+            assert pl < 1e-5, f"{name}: precision loss vs MKL {pl:.3e}"
+            out["vs_mkl"] = d
+    REPORT.append(out)
+    return out
+
+
+def run_set(torch, mats, label):
+    """mats: dicts with rp/ci/va/rows/cols.  One batch call over all of them, then every matrix alone."""
+    import pyhispmv
+    dev = torch.device("cuda", 0)
+    h = pyhispmv.FpgaHandle(*HW)
+    h.set_arena_bytes(64 << 30)
+    try:
+        for m in mats:
+            m["idx"] = h.create_sparse_handle_from_csr(m["rp"], m["ci"], m["va"], m["rows"], m["cols"])
+            assert m["idx"] >= 0
+        h.load_matrices()
+        for m in mats:
+            x, b = ref_vectors(m["rows"], m["cols"])
+            m["x"], m["b"] = x, b
+            m["dx"], m["db"] = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+            m["dy"] = torch.full((m["rows"],), float("nan"), dtype=torch.float32, device=dev)
+        batch = h.prepare_batch([m["idx"] for m in mats], [m["dx"].data_ptr() for m in mats],
+                                [m["db"].data_ptr() for m in mats], [m["dy"].data_ptr() for m in mats])
+        for _ in range(2):                      # the second call reuses the cached device tables
+            for m in mats:
+                m["dy"].fill_(float("nan"))
+            torch.cuda.synchronize()
+            h.spmv_device_batch(batch, ALPHA, BETA, 0)
+            h.synchronize()
+            torch.cuda.synchronize()
+        for m in mats:
+            yb = m["dy"].cpu().numpy()
+            info = h.matrix_info(m["idx"])
+            plan = f'{info["block_threads"]}t/{info["group_slices"]}s/{info["lds_bytes"] // 1024}KiB/{info["col_tiles"]}ct'
+            out = check_y(f'{label}:{m["name"]}:batch', yb, m["rp"], m["ci"], m["va"], m["cols"], m["x"], m["b"], ALPHA, BETA)
+            out["plan"] = plan
+            m["dy"].fill_(float("nan"))
+            torch.cuda.synchronize()
+            h.spmv_device(m["idx"], m["dx"].data_ptr(), m["db"].data_ptr(), m["dy"].data_ptr(), ALPHA, BETA, 0)
+            h.synchronize()
+            torch.cuda.synchronize()
+            ys = m["dy"].cpu().numpy()
+            check_y(f'{label}:{m["name"]}:single', ys, m["rp"], m["ci"], m["va"], m["cols"], m["x"], m["b"], ALPHA, BETA, mkl=False)
+            # beta = 0: bias is not read (MKL/BLAS convention); through the batch entry point with a NULL bias table
+            m["dy"].fill_(float("nan"))
+        torch.cuda.synchronize()
+        nb = h.prepare_batch([m["idx"] for m in mats], [m["dx"].data_ptr() for m in mats], None, [m["dy"].data_ptr() for m in mats])
+        h.spmv_device_batch(nb, ALPHA, 0.0, 0)
+        h.synchronize()
+        torch.cuda.synchronize()
+        for m in mats:
+            check_y(f'{label}:{m["name"]}:beta0', m["dy"].cpu().numpy(), m["rp"], m["ci"], m["va"], m["cols"], m["x"], m["b"],
+                    ALPHA, 0.0, mkl=False)
+    finally:
+        h.close()
+        for m in mats:
+            for k in ("dx", "db", "dy"):
+                m.pop(k, None)
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("family", ["structured", "uniform"])
+def test_suitesparse_set_as_benchmarked(torch_mod, family):
+    """BASELINE.json configs[1]: all 20 matrices at their real rows/nnz, with the plans that carry the headline number
+    (1024-thread resident windows, 2 column tiles, the shared multi-matrix grids)."""
+    from hispmv_amd import matrices as M
+    mats = M.benchmark_set(None, family == "uniform")
+    if family == "uniform":                       # the other 12 are identical in both families
+        mats = [m for m in mats if m.get("family") == "fem"]
+    mats = [m for m in mats if "rp" in m]         # (real files, if a user dropped them in, are covered by the CLI)
+    assert mats
+    run_set(torch_mod, mats, family)
+
+
+def coo_to_sorted_csr(r, c, v, rows):
+    order = np.lexsort((c, r))
+    rp = np.zeros(rows + 1, np.int64)
+    np.add.at(rp, np.asarray(r, np.int64) + 1, 1)
+    return np.cumsum(rp).astype(np.int32), np.asarray(c, np.int32)[order], np.asarray(v, np.float32)[order]
+
+
+def test_power_law_and_adversarial_matrices(torch_mod):
+    """BASELINE.json configs[2] / SURVEY.md 8(d) C3."""
+    from hispmv_amd import matrices as M
+    mats = []
+    n, _, r, c, v = M.rmat_coo(20)                                   # 16.8 M edges, duplicates kept
+    rp, ci, va = coo_to_sorted_csr(r, c, v, n)
+    mats.append(dict(name="rmat20", rows=n, cols=n, rp=rp, ci=ci, va=va))
+    rp, ci, va = M.zipf_csr(1632803, 1632803, 30622600, 1.2, 7)
+    mats.append(dict(name="zipf1.2_pokec_shape", rows=1632803, cols=1632803, rp=rp, ci=ci, va=va))
+    rp, ci, va = M.heavy_rows_csr(400000, 400000, 8000000)
+    mats.append(dict(name="1pct_rows_90pct_nnz", rows=400000, cols=400000, rp=rp, ci=ci, va=va))
+    rp, ci, va = M.full_row_plus_diagonal(1000000)
+    mats.append(dict(name="full_row_plus_diag", rows=1000000, cols=1000000, rp=rp, ci=ci, va=va))
+    run_set(torch_mod, mats, "C3")
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_model_test_layers_full_size(batch):
+    """BASELINE.json configs[3] / SURVEY.md 8(d) C4: the three layers of apps/model_test.py at their default size
+    through FpgaHandle.linear (alpha = beta = 1, fpga_handle.cpp:351-352), `batch` vectors per call."""
+    import pyhispmv
+    from hispmv_amd import matrices as M
+    layers = M.model_test_layers(0)
+    h = pyhispmv.FpgaHandle(*HW)
+    try:
+        for L in layers:
+            kind, W, rows, cols, bias = L
+            idx = h.create_dense_handle(W.reshape(-1), rows, cols) if kind == "dense" else h.create_sparse_handle(W[0], W[1], W[2], rows, cols)
+            assert idx >= 0
+        h.load_matrices()
+        rng = np.random.default_rng(5)
+        for idx, (kind, W, rows, cols, bias) in enumerate(layers):
+            x = rng.random(batch * cols, dtype=np.float32)
+            out = h.linear(idx, x, bias)
+            assert out.shape == (batch * rows,)
+            if kind == "dense":
+                rp = (np.arange(rows + 1, dtype=np.int64) * cols).astype(np.int32)
+                ci = np.tile(np.arange(cols, dtype=np.int32), rows)
+                va = W.reshape(-1)
+            else:
+                rp, ci, va = coo_to_sorted_csr(W[0], W[1], W[2], rows)
+            for k in range(batch):
+                check_y(f"C4:layer{idx}:{kind}:b{batch}:v{k}", out[k * rows:(k + 1) * rows], rp, ci, va, cols,
+                        x[k * cols:(k + 1) * cols], bias, 1.0, 1.0, mkl=(k == 0))
+            if batch > 1:       # a batched pass gives every vector the bits of its single-vector run
+                one = h.linear(idx, x[:cols], bias)
+                assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
+    finally:
+        h.close()
+
+
+def test_zz_write_parity_report():
+    """Keeps the figures of this module (runs last in the file): gpurun_out/parity_report.json on the GPU box."""
+    import json
+    import os
+    from pathlib import Path
+    assert REPORT, "no parity figures were collected"
+    root = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parents[1]))
+    out = root / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    worst = max(REPORT, key=lambda q: q["bwd"])
+    (out / "parity_report.json").write_text(json.dumps({"cases": REPORT, "worst_backward": worst}, indent=1) + "\n")
+    print(f"\n{len(REPORT)} result vectors; worst backward error {worst['bwd']:.2e} ({worst['name']}); "
+          f"worst plain relative error on non-cancelling rows {max(q['rel_well'] for q in REPORT):.2e}; "
+          f"over all rows {max(q['rel_all'] for q in REPORT):.2e}")

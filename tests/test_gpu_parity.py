@@ -385,6 +385,64 @@ def test_multi_matrix_launch_matches_each_matrix_alone(fpga):
                                                   [m0["db"].data_ptr(), m1["db"].data_ptr()], [m0["dy"].data_ptr()] * 2), 1.0, 1.0)
 
 
+def test_batch_tables_survive_the_first_host_vector_call(pyhispmv_mod):
+    """Regression (round 1, hispmv_abi.cpp run_host_vectors): the first staged run_kernel / linear of a context grew the
+    pinned staging block and, through a stray line, freed the device tables of earlier hispmv_spmv_device_batch calls
+    without forgetting them -- the next batch call with the same arguments launched on freed memory.  Sequence: batch,
+    first host-vector call (grows the stage), a few small device allocations that would reuse the freed fragments and
+    overwrite them, the same batch again: bit-identical results, and no free rejected by the runtime up to and
+    including hispmv_destroy."""
+    import torch
+    from hispmv_amd._lib import lib
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda", 0)
+    before = lib.hispmv_free_failures()
+    h = pyhispmv_mod.FpgaHandle(*HW)
+    mats = []
+    for rows, cols, nnz in ((5000, 4000, 90000), (12000, 12000, 300000), (300, 70000, 40000)):
+        r = rng.integers(0, rows, nnz).astype(np.int32)
+        r[: nnz // 5] = 7                                   # cut rows: the fix-up table is used too
+        c = rng.integers(0, cols, nnz).astype(np.int32)
+        v = rng.random(nnz, dtype=np.float32) - 0.5
+        mats.append(dict(idx=h.create_sparse_handle(r, c, v, rows, cols), rows=rows, cols=cols))
+    Wd = rng.standard_normal((64, 128), dtype=np.float32)
+    i_dense = h.create_dense_handle(Wd.flatten(), *Wd.shape)
+    h.load_matrices()
+    for m in mats:
+        m["dx"] = torch.from_numpy(rng.random(m["cols"], dtype=np.float32)).to(dev)
+        m["db"] = torch.from_numpy(rng.random(m["rows"], dtype=np.float32)).to(dev)
+        m["dy"] = torch.full((m["rows"],), float("nan"), dtype=torch.float32, device=dev)
+    batch = h.prepare_batch([m["idx"] for m in mats], [m["dx"].data_ptr() for m in mats], [m["db"].data_ptr() for m in mats],
+                            [m["dy"].data_ptr() for m in mats])
+    h.spmv_device_batch(batch, ALPHA, BETA)
+    h.synchronize()
+    first = [m["dy"].cpu().numpy().copy() for m in mats]
+    yd = np.zeros(64, np.float32)
+    h.select_matrix(i_dense)
+    h.run_kernel(rng.random(128, dtype=np.float32), rng.random(64, dtype=np.float32), yd, 1.0, 1.0)   # grows the stage
+    import ctypes as C
+    hip = C.CDLL(None)                                       # the HIP runtime already in the process (torch's copy)
+    junk = []
+    if hasattr(hip, "hipMalloc"):
+        for _ in range(64):                                  # raw small allocations: they take freed fragments first
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(2048)) == 0
+            assert hip.hipMemset(p, C.c_int(0xff), C.c_size_t(2048)) == 0
+            junk.append(p)
+        assert hip.hipDeviceSynchronize() == 0
+    for m in mats:
+        m["dy"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    h.spmv_device_batch(batch, ALPHA, BETA)                  # same key: the cached tables
+    h.synchronize()
+    for m, y0 in zip(mats, first):
+        assert np.array_equal(m["dy"].cpu().numpy().view(np.uint32), y0.view(np.uint32))
+    for p in junk:
+        assert hip.hipFree(p) == 0
+    h.close()
+    assert lib.hispmv_free_failures() == before
+
+
 @pytest.mark.parametrize("alpha,beta", [(ALPHA_HOST, BETA_HOST), (1.0, 0.0), (0.0, 1.0), (-1.5, 0.5)])
 def test_power_law_and_heavy_rows(fpga, alpha, beta):
     rng = np.random.default_rng(7)
