@@ -49,7 +49,11 @@ struct Matrix {
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0;
     int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
+    bool l2_tiles = false;      // the column tiles gather x through L2 (L2-sized tiles): pinned to XCD subsets in a batch call
     float* d_dense = nullptr;
+    // column tiles t > 0 write alpha*A_t*x here (tile t, vector v of a batched pass: d_ypart + ((t-1)*kMaxBatch + v)*rows);
+    // a merge pass adds them to y after the cut rows of every tile are fixed up
+    float* d_ypart = nullptr;
     std::vector<void*> allocs;
 };
 
@@ -78,15 +82,21 @@ struct hispmv_ctx {
     // cost ~65 us around a 20 us kernel)
     float* h_stage = nullptr;
     int64_t cap_stage = 0;
-    // hispmv_spmv_device_batch: device tables of the multi-matrix launches, keyed by what they describe
-    struct MultiTable {
-        std::vector<uint64_t> key;
-        std::vector<MultiEntry> entries;
-        std::vector<const SpmvDeviceMatrix*> parts;
-        std::vector<float*> ys;
-        void *d_entries = nullptr, *d_fix = nullptr;
+    // hispmv_spmv_device_batch: the launches of one call signature (handles, vectors, beta == 0 or not) with their device
+    // tables, built on the first call and replayed afterwards
+    struct BatchLaunch {
+        int kind = 0;                                   // 0 slice kernels of one workgroup size, 1 fix-up of cut rows, 2 merge of column-tile partial vectors
+        std::vector<const SpmvDeviceMatrix*> parts;     // kinds 0, 1
+        std::vector<float*> ys;                         // kind 1: where each part's cut rows live (y or a partial vector)
+        std::vector<int32_t> rows;                      // kind 2
+        std::vector<uint8_t> item_tiles;                // kind 0: parts per item (> 1: the XCD-pinned column tiles of one matrix)
+        void* d_table = nullptr;
     };
-    std::vector<MultiTable> multi_tables;
+    struct BatchPlan {
+        std::vector<uint64_t> key;
+        std::vector<BatchLaunch> launches;
+    };
+    std::vector<BatchPlan> batch_plans;
     // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
     // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
     // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.
@@ -130,6 +140,12 @@ template <class T> void host_free(T*& p) {
     p = nullptr;
 }
 
+void free_batch_plans(hispmv_ctx* c) {
+    for (auto& p : c->batch_plans)
+        for (auto& l : p.launches) dev_free(l.d_table);
+    c->batch_plans.clear();
+}
+
 int64_t sparse_device_bytes(const SliceStream& st) {
     return (int64_t)st.words.size() * 8 + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
            (int64_t)st.n_slices * 12 + 8;
@@ -150,7 +166,7 @@ void free_matrix_device(Matrix& m) {
     for (void*& p : m.allocs) dev_free(p);
     m.allocs.clear();
     for (auto& p : m.parts) p.dev = SpmvDeviceMatrix{};
-    m.d_dense = nullptr;
+    m.d_dense = nullptr; m.d_ypart = nullptr;
     m.loaded = false;
 }
 
@@ -194,7 +210,10 @@ Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
 // L2, i.e. tiles of 2-4 MiB; HISPMV_COL_TILE_BYTES overrides, 0 disables).
 int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
     if (tile_bytes <= 0 || (int64_t)cols * 4 <= tile_bytes + tile_bytes / 2) return 0;
-    const int64_t tiles = ((int64_t)cols * 4 + tile_bytes - 1) / tile_bytes;
+    // 2, 4 or 8 tiles: in a batch call the tiles of a matrix run in the same round, each pinned to 8 / tiles of the
+    // 8 XCDs, so that an XCD's L2 holds one tile's part of x (more than 8 tiles' worth of x: 8 larger tiles)
+    int64_t tiles = ((int64_t)cols * 4 + tile_bytes - 1) / tile_bytes;
+    tiles = tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
     const int64_t w = (((int64_t)cols + tiles - 1) / tiles + 63) & ~63LL;     // equal tiles, 256-byte aligned
     return (int32_t)w;
 }
@@ -274,6 +293,11 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
             m->parts.emplace_back();
             m->parts[0].st = build_stream(csr);
             finish_part(m->parts[0], c->n_cus);
+        } else if (!lds_goal) {
+            const size_t np = m->parts.size();
+            bool same = np == 2 || np == 4 || np == 8;
+            for (auto& p : m->parts) same = same && p.plan.block_threads == m->parts[0].plan.block_threads && p.plan.lds_floats == 0;
+            m->l2_tiles = same;
         }
     }
     csr = Csr{};
@@ -281,6 +305,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
         m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
         m->device_bytes += sparse_device_bytes(p.st) + (int64_t)p.plan.groups.size() * 16 + (int64_t)p.plan.frags.size() * 16;
     }
+    if (m->parts.size() > 1) m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of tiles t > 0
     m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
     m->plan_lds = m->parts[0].plan.lds_floats;
     m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -310,10 +335,14 @@ int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bia
         return HISPMV_OK;
     }
     for (size_t t = 0; t < m.parts.size(); ++t) {
-        // column tile t > 0 accumulates on top of what the earlier tiles wrote: beta = 1, bias = y
+        // column tile 0 computes alpha*A_0*x + beta*bias into y; tile t > 0 writes alpha*A_t*x into its partial vector
         hipError_t e = (t == 0) ? launch_spmv(m.parts[t].dev, d_x, d_bias, d_y, alpha, beta, s)
-                                : launch_spmv(m.parts[t].dev, d_x, d_y, d_y, alpha, 1.0f, s);
+                                : launch_spmv(m.parts[t].dev, d_x, nullptr, m.d_ypart + (t - 1) * (size_t)kMaxBatch * m.rows, alpha, 0.0f, s);
         if (e != hipSuccess) return hip_fail(c, e, "launch_spmv");
+    }
+    if (m.parts.size() > 1) {
+        hipError_t e = launch_merge_parts(d_y, m.d_ypart, (int)m.parts.size() - 1, (int64_t)kMaxBatch * m.rows, m.rows, 1, 0, 0, s);
+        if (e != hipSuccess) return hip_fail(c, e, "launch_merge_parts");
     }
     return HISPMV_OK;
 }
@@ -330,8 +359,8 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
     }
     int64_t k = 0;
     while (k < vecs) {
-        int nv = kMaxBatch;
-        for (auto& p : m.parts) nv = std::min(nv, spmv_batch_width(p.dev, vecs - k, beta));
+        int nv = beta != 0.0f ? kMaxBatch : 1;       // (linear always has beta = 1; the batched kernel's tile 0 reads a bias)
+        for (auto& p : m.parts) nv = std::min(nv, spmv_batch_width(p.dev, vecs - k));
         const float* xk = d_x + k * m.cols;
         float* yk = d_y + k * m.rows;
         if (nv < 2) {
@@ -341,10 +370,14 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
             continue;
         }
         for (size_t t = 0; t < m.parts.size(); ++t) {
-            // column tile t > 0 accumulates on what the earlier tiles wrote: beta = 1, bias = each vector's own y
+            // tile 0: shared bias; tile t > 0: the nv partial vectors of that tile, no bias
             hipError_t e = (t == 0) ? launch_spmv_batched(m.parts[t].dev, nv, xk, d_bias, 0, yk, alpha, beta, s)
-                                    : launch_spmv_batched(m.parts[t].dev, nv, xk, yk, m.rows, yk, alpha, 1.0f, s);
+                                    : launch_spmv_batched(m.parts[t].dev, nv, xk, nullptr, 0, m.d_ypart + (t - 1) * (size_t)kMaxBatch * m.rows, alpha, 0.0f, s);
             if (e != hipSuccess) return hip_fail(c, e, "launch_spmv_batched");
+        }
+        if (m.parts.size() > 1) {
+            hipError_t e = launch_merge_parts(yk, m.d_ypart, (int)m.parts.size() - 1, (int64_t)kMaxBatch * m.rows, m.rows, nv, m.rows, m.rows, s);
+            if (e != hipSuccess) return hip_fail(c, e, "launch_merge_parts");
         }
         k += nv;
     }
@@ -427,8 +460,7 @@ HISPMV_API void hispmv_destroy(hispmv_ctx* c) {
     dev_free(c->d_y);
     host_free(c->h_err);
     host_free(c->h_stage);
-    for (auto& t : c->multi_tables) { dev_free(t.d_entries); dev_free(t.d_fix); }
-    c->multi_tables.clear();
+    free_batch_plans(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -597,6 +629,12 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.use_ticket = c->carry_mode == 3;
             }
         }
+        if (!m.dense && m.parts.size() > 1) {
+            void* yp = nullptr;
+            HIP_TRY(c, hipMalloc(&yp, (m.parts.size() - 1) * (size_t)kMaxBatch * m.rows * sizeof(float)));
+            m.allocs.push_back(yp);
+            m.d_ypart = (float*)yp;
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // host copies are no longer needed
         for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; p.plan.frags = {}; }
@@ -687,52 +725,102 @@ HISPMV_API int hispmv_spmv_device(hispmv_ctx* c, int idx, const float* d_x, cons
     return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, stream ? (hipStream_t)stream : c->stream);
 }
 
-// One multi-matrix launch for `sel` (indices into the caller's arrays; part `r` of each matrix): the slice kernels when
-// `fixup` is false (all of `sel` have the same workgroup size), the fix-up of their cut rows when it is true.
-static int launch_multi_class(hispmv_ctx* c, const std::vector<int>& sel, int r, bool fixup, const int32_t* idx,
-                              const float* const* d_x, const float* const* d_bias, float* const* d_y, float alpha, float beta,
-                              hipStream_t s) {
-    std::vector<uint64_t> key{(uint64_t)r, (uint64_t)fixup, (uint64_t)sel.size()};
-    for (int i : sel) {
-        key.push_back((uint64_t)idx[i]); key.push_back((uint64_t)(uintptr_t)d_x[i]);
-        key.push_back((uint64_t)(uintptr_t)(r == 0 ? d_bias[i] : d_y[i])); key.push_back((uint64_t)(uintptr_t)d_y[i]);
-    }
-    hispmv_ctx::MultiTable* tab = nullptr;
-    for (auto& t : c->multi_tables) if (t.key == key) { tab = &t; break; }
-    if (!tab) {
-        if (c->multi_tables.size() >= 64) {      // callers that keep changing their vectors: start over
-            for (auto& t : c->multi_tables) { dev_free(t.d_entries); dev_free(t.d_fix); }
-            c->multi_tables.clear();
-        }
-        hispmv_ctx::MultiTable t;
-        t.key = key;
-        std::vector<MultiFixEntry> fix;
-        for (int i : sel) {
-            SpmvDeviceMatrix& d = c->mats[idx[i]]->parts[(size_t)r].dev;
-            MultiEntry e{};
-            e.words = d.words; e.hdr = d.hdr; e.groups = d.groups; e.frags = d.frags;
-            e.x = d_x[i]; e.bias = r == 0 ? d_bias[i] : d_y[i]; e.y = d_y[i]; e.carry = d.carry;
-            e.n_slices = d.n_slices; e.group_slices = d.group_slices; e.lds_floats = d.lds_floats; e.ytile_floats = d.ytile_floats;
-            e.cols = d.cols; e.rows = d.rows;
-            t.entries.push_back(e);
-            t.parts.push_back(&d);
-            t.ys.push_back(d_y[i]);
-            fix.push_back(MultiFixEntry{d.fix_short, d.carry, d_y[i], d.n_fix_short, 0});
-        }
-        if (fixup) {
-            HIP_TRY(c, hipMalloc(&t.d_fix, fix.size() * sizeof(MultiFixEntry)));
-            HIP_TRY(c, hipMemcpy(t.d_fix, fix.data(), fix.size() * sizeof(MultiFixEntry), hipMemcpyHostToDevice));
+// Builds the launches of a batch call: every column tile of every sparse handle is one "part"; parts with the same
+// workgroup size share a grid (largest first, so that the small ones fill the tail), ONE fix-up launch finishes the cut
+// rows of all parts (each on its own output: y for tile 0, the handle's partial vector for tile t > 0), ONE merge launch
+// adds the partial vectors of the column-tiled matrices to their y.
+static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t n, const int32_t* idx, const float* const* d_x,
+                            const float* const* bias, float* const* d_y, float beta) {
+    struct Ref { int i; size_t t; };
+    struct Item { std::vector<Ref> refs; int threads; int64_t slices; };
+    std::vector<Item> items;
+    std::vector<Ref> refs;
+    auto dev_of = [&](const Ref& r) -> SpmvDeviceMatrix& { return c->mats[idx[r.i]]->parts[r.t].dev; };
+    auto out_of = [&](const Ref& r) -> float* {
+        Matrix& m = *c->mats[idx[r.i]];
+        return r.t == 0 ? d_y[r.i] : m.d_ypart + (r.t - 1) * (size_t)kMaxBatch * m.rows;
+    };
+    const bool pin = !std::getenv("HISPMV_NO_XCD_PIN");
+    for (int i = 0; i < n; ++i) {
+        const Matrix& m = *c->mats[idx[i]];
+        if (m.dense) continue;
+        if (m.l2_tiles && pin) {                 // the L2-sized column tiles of a matrix: one item, pinned to XCD subsets
+            Item it{{}, m.parts[0].dev.block_threads, 0};
+            for (size_t t = 0; t < m.parts.size(); ++t) { it.refs.push_back(Ref{i, t}); it.slices += m.parts[t].dev.n_slices; }
+            items.push_back(std::move(it));
         } else {
-            HIP_TRY(c, hipMalloc(&t.d_entries, t.entries.size() * sizeof(MultiEntry)));
-            HIP_TRY(c, hipMemcpy(t.d_entries, t.entries.data(), t.entries.size() * sizeof(MultiEntry), hipMemcpyHostToDevice));
+            for (size_t t = 0; t < m.parts.size(); ++t) items.push_back(Item{{Ref{i, t}}, m.parts[t].dev.block_threads, m.parts[t].dev.n_slices});
         }
-        c->multi_tables.push_back(std::move(t));
-        tab = &c->multi_tables.back();
     }
-    hipError_t e = fixup ? launch_fixup_multi(tab->parts.data(), tab->ys.data(), (int)tab->parts.size(), (const MultiFixEntry*)tab->d_fix, alpha, s)
-                         : launch_spmv_multi(tab->parts.data(), (int)tab->parts.size(), (const MultiEntry*)tab->d_entries, alpha, beta, s);
-    if (e != hipSuccess) return hip_fail(c, e, fixup ? "launch_fixup_multi" : "launch_spmv_multi");
-    return HISPMV_OK;
+    std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) {
+        if (a.threads != b.threads) return a.threads > b.threads;
+        return a.slices > b.slices;
+    });
+    for (const Item& it : items) for (const Ref& r : it.refs) refs.push_back(r);
+    auto upload_table = [&](hispmv_ctx::BatchLaunch& l, const void* host, size_t bytes) -> int {
+        HIP_TRY(c, hipMalloc(&l.d_table, bytes));
+        HIP_TRY(c, hipMemcpy(l.d_table, host, bytes, hipMemcpyHostToDevice));
+        return HISPMV_OK;
+    };
+    int rc;
+    for (size_t k = 0; k < items.size();) {                     // slice kernels, one launch per class
+        const int threads = items[k].threads;
+        hispmv_ctx::BatchLaunch l;
+        l.kind = 0;
+        std::vector<MultiEntry> entries;
+        while (k < items.size() && items[k].threads == threads && entries.size() + items[k].refs.size() <= (size_t)kMultiMax) {
+            for (const Ref& r : items[k].refs) {
+                SpmvDeviceMatrix& d = dev_of(r);
+                MultiEntry e{};
+                e.words = d.words; e.hdr = d.hdr; e.groups = d.groups; e.frags = d.frags;
+                e.x = d_x[r.i]; e.bias = r.t == 0 ? bias[r.i] : nullptr; e.y = out_of(r); e.carry = d.carry;
+                e.n_slices = d.n_slices; e.group_slices = d.group_slices; e.lds_floats = d.lds_floats; e.ytile_floats = d.ytile_floats;
+                e.cols = d.cols; e.rows = d.rows;
+                e.beta = r.t == 0 ? beta : 0.0f;
+                entries.push_back(e);
+                l.parts.push_back(&d);
+            }
+            l.item_tiles.push_back((uint8_t)items[k].refs.size());
+            ++k;
+        }
+        plan.launches.push_back(std::move(l));
+        if ((rc = upload_table(plan.launches.back(), entries.data(), entries.size() * sizeof(MultiEntry))) != HISPMV_OK) return rc;
+    }
+    for (size_t k = 0; k < refs.size(); k += kMultiMax) {       // fix-up of the cut rows
+        hispmv_ctx::BatchLaunch l;
+        l.kind = 1;
+        std::vector<MultiFixEntry> fix;
+        bool any = false;
+        for (size_t q = k; q < std::min(refs.size(), k + kMultiMax); ++q) {
+            SpmvDeviceMatrix& d = dev_of(refs[q]);
+            fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(refs[q]), d.n_fix_short, 0});
+            l.parts.push_back(&d);
+            l.ys.push_back(out_of(refs[q]));
+            any = any || d.n_fix_short > 0 || d.n_fix_long > 0;
+        }
+        if (!any) continue;
+        plan.launches.push_back(std::move(l));
+        if ((rc = upload_table(plan.launches.back(), fix.data(), fix.size() * sizeof(MultiFixEntry))) != HISPMV_OK) return rc;
+    }
+    std::vector<MultiMergeEntry> merges;
+    std::vector<int32_t> merge_rows;
+    auto flush_merges = [&]() -> int {
+        if (merges.empty()) return HISPMV_OK;
+        hispmv_ctx::BatchLaunch l;
+        l.kind = 2; l.rows = merge_rows;
+        plan.launches.push_back(std::move(l));
+        const int r2 = upload_table(plan.launches.back(), merges.data(), merges.size() * sizeof(MultiMergeEntry));
+        merges.clear(); merge_rows.clear();
+        return r2;
+    };
+    for (int i = 0; i < n; ++i) {                               // merge of the column-tile partial vectors
+        Matrix& m = *c->mats[idx[i]];
+        if (m.dense || m.parts.size() < 2) continue;
+        merges.push_back(MultiMergeEntry{d_y[i], m.d_ypart, (long long)kMaxBatch * m.rows, (int32_t)m.parts.size() - 1, m.rows});
+        merge_rows.push_back(m.rows);
+        if ((int)merges.size() == kMultiMax && (rc = flush_merges()) != HISPMV_OK) return rc;
+    }
+    return flush_merges();
 }
 
 HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t* idx, const float* const* d_x,
@@ -740,7 +828,6 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
     if (!c) return HISPMV_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     if (n < 0 || (n > 0 && (!idx || !d_x || !d_y || (beta != 0.0f && !d_bias)))) return fail(c, HISPMV_EINVAL, "NULL argument");
-    size_t rounds = 0;
     for (int i = 0; i < n; ++i) {
         if (idx[i] < 0 || idx[i] >= (int)c->mats.size()) return fail(c, HISPMV_EINVAL, "Matrix idx out of range");
         const Matrix& m = *c->mats[idx[i]];
@@ -751,7 +838,6 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
             // the carry buffers of cut rows belong to the handle: one SpMV per handle at a time (hispmv.h, threading)
             if (idx[k] == idx[i] && !m.dense) return fail(c, HISPMV_EINVAL, "the same sparse handle twice in one batch");
         }
-        if (!m.dense) rounds = std::max(rounds, m.parts.size());
     }
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -765,40 +851,32 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
         int rc = launch_matrix(c, m, d_x[i], bias[i], d_y[i], alpha, beta, s);
         if (rc != HISPMV_OK) return rc;
     }
-    // round r = column tile r of every matrix that has one (tile r > 0 accumulates on y: beta = 1, bias = y); inside a
-    // round the matrices are grouped by workgroup size, largest first so that the small ones fill the tail of the grid
-    for (size_t r = 0; r < rounds; ++r) {
-        std::vector<int> order;
-        for (int i = 0; i < n; ++i) {
-            const Matrix& m = *c->mats[idx[i]];
-            if (!m.dense && m.parts.size() > r) order.push_back(i);
+    // the launches of this call signature: built once, replayed afterwards (beta enters the tables; alpha is a kernel argument)
+    std::vector<uint64_t> key{(uint64_t)n, (uint64_t)__builtin_bit_cast(uint32_t, beta)};
+    for (int i = 0; i < n; ++i) {
+        key.push_back((uint64_t)idx[i]); key.push_back((uint64_t)(uintptr_t)d_x[i]);
+        key.push_back((uint64_t)(uintptr_t)(beta != 0.0f ? bias[i] : nullptr)); key.push_back((uint64_t)(uintptr_t)d_y[i]);
+    }
+    hispmv_ctx::BatchPlan* plan = nullptr;
+    for (auto& p : c->batch_plans) if (p.key == key) { plan = &p; break; }
+    if (!plan) {
+        if (c->batch_plans.size() >= 16) free_batch_plans(c);      // callers that keep changing their vectors: start over
+        c->batch_plans.emplace_back();
+        c->batch_plans.back().key = key;
+        const int rc = build_batch_plan(c, c->batch_plans.back(), n, idx, d_x, bias, d_y, beta);
+        if (rc != HISPMV_OK) {                                      // nothing half-built stays behind
+            for (auto& l : c->batch_plans.back().launches) dev_free(l.d_table);
+            c->batch_plans.pop_back();
+            return rc;
         }
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            const SpmvDeviceMatrix& da = c->mats[idx[a]]->parts[r].dev; const SpmvDeviceMatrix& db = c->mats[idx[b]]->parts[r].dev;
-            if (da.block_threads != db.block_threads) return da.block_threads > db.block_threads;
-            return da.n_slices > db.n_slices;
-        });
-        std::vector<std::vector<int>> classes;
-        for (size_t k = 0; k < order.size();) {
-            const int threads = c->mats[idx[order[k]]]->parts[r].dev.block_threads;
-            std::vector<int> sel;
-            while (k < order.size() && (int)sel.size() < kMultiMax && c->mats[idx[order[k]]]->parts[r].dev.block_threads == threads) sel.push_back(order[k++]);
-            classes.push_back(std::move(sel));
-        }
-        // (a class of one goes the same way: every matrix of a batch call uses the fix-up carry variant)
-        const float beta_r = r == 0 ? beta : 1.0f;
-        // the classes of a round run one after the other on the caller's stream (side streams were tried: an HBM-bound
-        // class and an L2-request-bound class do not overlap, 474 vs 470 us per step of the 20-matrix set), then ONE
-        // fix-up launch finishes the cut rows of the whole round
-        for (const auto& sel : classes) {
-            const int rc = launch_multi_class(c, sel, (int)r, false, idx, d_x, bias, d_y, alpha, beta_r, s);
-            if (rc != HISPMV_OK) return rc;
-        }
-        for (size_t k = 0; k < order.size(); k += kMultiMax) {
-            const std::vector<int> sel(order.begin() + (long)k, order.begin() + (long)std::min(order.size(), k + kMultiMax));
-            const int rc = launch_multi_class(c, sel, (int)r, true, idx, d_x, bias, d_y, alpha, beta_r, s);
-            if (rc != HISPMV_OK) return rc;
-        }
+        plan = &c->batch_plans.back();
+    }
+    for (const auto& l : plan->launches) {
+        hipError_t e = hipSuccess;
+        if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, s);
+        else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, s);
+        else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, s);
+        if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : "launch_merge_multi");
     }
     return HISPMV_OK;
 }

@@ -46,12 +46,24 @@ struct MultiEntry {
     const uint64_t* words; const int4* hdr; const int4* groups; const int4* frags;
     const float* x; const float* bias; float* y; float* carry;
     long long n_slices;
-    int32_t group_slices, lds_floats, ytile_floats, cols, rows, pad;
+    int32_t group_slices, lds_floats, ytile_floats, cols, rows;
+    float beta;                     // per entry: 0 for the column tiles t > 0 of a matrix (they write partial vectors, no bias)
 };
 struct MultiFixEntry { const int4* fix; const float* carry; float* y; int32_t n, pad; };
+struct MultiMergeEntry { float* y; const float* parts; long long part_stride; int32_t n_parts, rows; };
 // ... and, as a kernel argument, where each entry's workgroups begin in the grid (begin[n] = grid size)
+// An ITEM of a multi launch is one table entry, or -- `tiles[k]` = 2, 4 or 8 -- the column tiles of one matrix that
+// gather x through L2: consecutive table entries from `first[k]`, pinned to disjoint XCD subsets.  Workgroups are dealt
+// round-robin over the 8 XCDs (MI355X_MICROARCH.md, workgroup dispatch), so blocks with the same index mod 8 share an
+// L2; the item's range starts at a multiple of 8 and block q of it belongs to tile (q % 8) / (8 / tiles): every XCD then
+// serves ONE tile and its L2 holds that tile's part of x, while all tiles run in the same round.
 constexpr int kMultiMax = 32;
-struct MultiPrefix { int32_t n, pad; long long begin[kMultiMax + 1]; };
+struct MultiPrefix {
+    int32_t n, pad;
+    long long begin[kMultiMax + 1];
+    uint8_t first[kMultiMax];
+    uint8_t tiles[kMultiMax];
+};
 
 constexpr int kFixShortMax = 32;
 constexpr int kMaxBatch = 4;                // vectors one pass of the batched slice kernel takes (carry holds kMaxBatch * n_slices)
@@ -67,16 +79,23 @@ hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, f
 // Batched SpMV (linear with several vectors): how many vectors (4, 2 or 1 = use launch_spmv) one pass can take for
 // this matrix, and the launch: vector v is x + v*cols -> y + v*rows; bias_stride 0 (shared) or rows (per vector).
 // Fix-up carry variant whatever m.lookback says: per vector bitwise equal to launch_spmv with lookback = false.
-int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs, float beta);
+int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs);
 hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, const float* bias, int bias_stride, float* y,
                                float alpha, float beta, hipStream_t stream);
 
 // Multi-matrix launch: `n` (<= kMultiMax) matrix parts with the same workgroup size in one grid, each writing carry[]
 // for rows cut by slice boundaries; `d_table` is the device copy of their MultiEntry descriptors (the caller owns and
-// caches it).  beta == 0 selects the variant without bias.  launch_fixup_multi then finishes the cut rows of `n` parts
+// caches it); every entry carries its own beta (0 = no bias read).  launch_fixup_multi then finishes the cut rows of `n` parts
 // (any workgroup sizes) in one launch; parts with fix_long rows get their own extra launch.
-hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const MultiEntry* d_table,
-                             float alpha, float beta, hipStream_t stream);
+// `item_tiles` (n_items entries summing to n; NULL = all 1) groups consecutive parts into XCD-pinned column-tile sets.
+hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const uint8_t* item_tiles, int n_items,
+                             const MultiEntry* d_table, float alpha, hipStream_t stream);
+// y += parts[0] + parts[1] + ... (column tiles t > 0 of one matrix, each of `rows` floats, `part_stride` apart); nv vectors
+// of a batched pass: vector v is y + v*y_stride, its partial vectors parts + v*vec_stride.
+hipError_t launch_merge_parts(float* y, const float* parts, int n_parts, int64_t part_stride, int32_t rows, int nv,
+                              int64_t y_stride, int64_t vec_stride, hipStream_t stream);
+// The same for `n` matrices in one launch (d_table: device copy of their MultiMergeEntry descriptors).
+hipError_t launch_merge_multi(const int32_t* rows, int n, const MultiMergeEntry* d_table, hipStream_t stream);
 hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const* ys, int n, const MultiFixEntry* d_fix_table,
                               float alpha, hipStream_t stream);
 

@@ -430,17 +430,29 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
 // SpMVs -- the 20 matrices of the benchmark set, the heads of a model -- then share launch ramps and tails instead of
 // paying 6-20 us of launch latency each.  All matrices of a launch have the same workgroup size.
 // ---------------------------------------------------------------------------
-template <bool HAS_BETA>
-__global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix,
-                                                                 float alpha, float beta) {
-    int e = 0;
+__global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
+    int k = 0;
 #pragma unroll 1
-    while (e + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[e + 1]) ++e;
+    while (k + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[k + 1]) ++k;
+    long long group = (long long)blockIdx.x - prefix.begin[k];
+    int e = prefix.first[k];
+    const int tiles = prefix.tiles[k];
+    if (tiles > 1) {              // XCD-pinned column tiles (hispmv_kernels.h): tile from the block's index mod 8
+        const int per = 8 / tiles, res = (int)(group & 7);
+        e += res / per;
+        group = (group >> 3) * per + (res % per);
+    }
     const MultiEntry t = table[e];
+    if (group * t.group_slices >= t.n_slices) return;      // (a pinned tile with fewer groups than its siblings)
     const LookbackArgs lb{};
-    slices_body<HAS_BETA, true, false>((const uint4*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, beta,
-                                       t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb,
-                                       (long long)blockIdx.x - prefix.begin[e]);
+    // beta is per entry: the first column tile of a matrix applies beta*bias, its other tiles write alpha*A_t*x into the
+    // handle's partial vectors (no bias read) -- both kinds share the grid, a workgroup runs one of the two bodies
+    if (t.beta != 0.0f)
+        slices_body<true, true, false>((const uint4*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, t.beta,
+                                       t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
+    else
+        slices_body<false, true, false>((const uint4*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, alpha, 0.0f,
+                                        t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
 }
 
 // Fix-up of all matrices of a multi launch: thread blocks are concatenated the same way.
@@ -457,6 +469,31 @@ __global__ __launch_bounds__(256) void spmv_fixup_multi_kernel(const MultiFixEnt
     t.y[f.x] += alpha * s;
 }
 
+// Column tiles t > 0 of a matrix write alpha*A_t*x into partial vectors of the handle (so that every tile runs in the
+// same round as tile 0 instead of accumulating in place behind it); after the fix-up of the cut rows this pass adds them:
+// y = ((y + part_1) + part_2) + ...   parts[t] = parts + t*part_stride; grid.y = vector of a batched pass.
+__global__ __launch_bounds__(256) void spmv_merge_parts_kernel(float* __restrict__ y, const float* __restrict__ parts, int n_parts,
+                                                               long long part_stride, int rows, long long y_stride, long long vec_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    y += blockIdx.y * y_stride;
+    parts += blockIdx.y * vec_stride;
+    float s = y[i];
+    for (int t = 0; t < n_parts; ++t) s += parts[(size_t)t * part_stride + i];
+    y[i] = s;
+}
+__global__ __launch_bounds__(256) void spmv_merge_multi_kernel(const MultiMergeEntry* __restrict__ table, MultiPrefix prefix) {
+    int e = 0;
+#pragma unroll 1
+    while (e + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[e + 1]) ++e;
+    const MultiMergeEntry t = table[e];
+    const int i = (int)(blockIdx.x - prefix.begin[e]) * blockDim.x + threadIdx.x;
+    if (i >= t.rows) return;
+    float s = t.y[i];
+    for (int k = 0; k < t.n_parts; ++k) s += t.parts[(size_t)k * t.part_stride + i];
+    t.y[i] = s;
+}
+
 // ---------------------------------------------------------------------------
 // Batched slice kernel: NV input vectors per pass over the stream (FpgaHandle::linear with num_vecs > 1; the
 // reference runs its kernel once per vector, fpga_handle.cpp:366-379 -- A is read num_vecs times).  Vector v
@@ -467,7 +504,7 @@ __global__ __launch_bounds__(256) void spmv_fixup_multi_kernel(const MultiFixEnt
 // slice is requested after the last vector's products.  The x windows of the NV vectors sit side by side in LDS.
 // Host guarantees: cols % 4 == 0 when USE_LDS, cols*NV < 2^30, rows*NV < 2^30, NV*lds_floats + tiles fit LDS.
 // ---------------------------------------------------------------------------
-template <bool USE_LDS, int NV>
+template <bool HAS_BETA, bool USE_LDS, int NV>
 __global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
     const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags,
@@ -541,8 +578,11 @@ __global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
         for (int v = 0; v < NV; ++v) {
             const unsigned xoff = (unsigned)v * (unsigned)cols, yoff = (unsigned)v * (unsigned)rows;
             const unsigned boff = (unsigned)v * (unsigned)bias_stride;
-            const float bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (boff + row_first + lane) << 2 : kNoAccess, 0, 0));
-            const float bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (boff + row_first + lane + 64) << 2 : kNoAccess, 0, 0));
+            float bpre0 = 0.0f, bpre1 = 0.0f;
+            if (HAS_BETA) {
+                bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (boff + row_first + lane) << 2 : kNoAccess, 0, 0));
+                bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (boff + row_first + lane + 64) << 2 : kNoAccess, 0, 0));
+            }
             float x0[kSliceSteps], x1[kSliceSteps];
             const float* xw = xs + v * lds_floats;
             if (USE_LDS && in_lds && !spills) {
@@ -610,9 +650,13 @@ __global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
             }
             for (int i = lane; i < n_rows; i += 64) {
                 const float t = ytile[i];
-                const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
-                              : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (boff + row_first + i) << 2, 0, 0));
-                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (yoff + row_first + i) << 2, 0, 0);
+                if (HAS_BETA) {
+                    const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
+                                  : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (boff + row_first + i) << 2, 0, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (yoff + row_first + i) << 2, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, (yoff + row_first + i) << 2, 0, 0);
+                }
             }
             if (lane == 0) carry[(long long)v * n_slices + cur] = carry_step;
         }
@@ -711,25 +755,25 @@ hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, f
     return hipGetLastError();
 }
 
-template <bool USE_LDS, int NV>
+template <bool HAS_BETA, bool USE_LDS, int NV>
 static hipError_t launch_batched(const SpmvDeviceMatrix& m, const float* x, const float* bias, int bias_stride, float* y,
                                  float alpha, float beta, hipStream_t stream) {
     const size_t lds = ((USE_LDS ? (size_t)m.lds_floats * NV : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float);
     static bool raised = false;      // per instantiation
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)spmv_slices_batched_kernel<USE_LDS, NV>,
+        hipError_t e = hipFuncSetAttribute((const void*)spmv_slices_batched_kernel<HAS_BETA, USE_LDS, NV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((spmv_slices_batched_kernel<USE_LDS, NV>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
+    hipLaunchKernelGGL((spmv_slices_batched_kernel<HAS_BETA, USE_LDS, NV>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
                        (const uint4*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
                        (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, bias_stride);
     return hipGetLastError();
 }
 
-int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs, float beta) {
-    if (beta == 0.0f || vecs < 2) return 1;           // (linear always has beta = 1)
+int spmv_batch_width(const SpmvDeviceMatrix& m, int64_t vecs) {
+    if (vecs < 2) return 1;
     if (m.lds_floats > 0 && (m.cols & 3)) return 1;   // the windows of vectors 1.. would be staged from unaligned rows of x
     for (int nv = kMaxBatch; nv >= 2; nv >>= 1) {
         if (nv > vecs) continue;
@@ -748,10 +792,16 @@ hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, cons
         if (m.n_groups <= 0 || m.n_groups > 0x7fffffffLL) return hipErrorInvalidValue;
         const bool lds = m.lds_floats > 0;
         hipError_t e;
-        if (nv == 4) e = lds ? launch_batched<true, 4>(m, x, bias, bias_stride, y, alpha, beta, stream)
-                             : launch_batched<false, 4>(m, x, bias, bias_stride, y, alpha, beta, stream);
-        else         e = lds ? launch_batched<true, 2>(m, x, bias, bias_stride, y, alpha, beta, stream)
-                             : launch_batched<false, 2>(m, x, bias, bias_stride, y, alpha, beta, stream);
+        const bool hb = beta != 0.0f;
+        if (!hb) bias = y;      // never read; keeps the buffer descriptor well-formed
+        if (nv == 4) e = hb ? (lds ? launch_batched<true, true, 4>(m, x, bias, bias_stride, y, alpha, beta, stream)
+                                   : launch_batched<true, false, 4>(m, x, bias, bias_stride, y, alpha, beta, stream))
+                            : (lds ? launch_batched<false, true, 4>(m, x, bias, bias_stride, y, alpha, beta, stream)
+                                   : launch_batched<false, false, 4>(m, x, bias, bias_stride, y, alpha, beta, stream));
+        else         e = hb ? (lds ? launch_batched<true, true, 2>(m, x, bias, bias_stride, y, alpha, beta, stream)
+                                   : launch_batched<true, false, 2>(m, x, bias, bias_stride, y, alpha, beta, stream))
+                            : (lds ? launch_batched<false, true, 2>(m, x, bias, bias_stride, y, alpha, beta, stream)
+                                   : launch_batched<false, false, 2>(m, x, bias, bias_stride, y, alpha, beta, stream));
         if (e != hipSuccess) return e;
     }
     if (m.n_fix_short > 0)     // one fix-up launch for all vectors of the pass (grid.y = vector)
@@ -763,35 +813,66 @@ hipError_t launch_spmv_batched(SpmvDeviceMatrix& m, int nv, const float* x, cons
     return hipGetLastError();
 }
 
-hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const MultiEntry* d_table,
-                             float alpha, float beta, hipStream_t stream) {
+hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const uint8_t* item_tiles, int n_items,
+                             const MultiEntry* d_table, float alpha, hipStream_t stream) {
     (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
+    if (n <= 0) return hipSuccess;
+    if (n > kMultiMax) return hipErrorInvalidValue;
+    if (!item_tiles) n_items = n;
+    MultiPrefix px{};
+    px.n = n_items;
+    long long g = 0;
+    size_t lds = 0;
+    const int threads = parts[0]->block_threads;
+    int e = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const int tiles = item_tiles ? item_tiles[k] : 1;
+        if (tiles != 1 && tiles != 2 && tiles != 4 && tiles != 8) return hipErrorInvalidValue;
+        if (e + tiles > n) return hipErrorInvalidValue;
+        if (tiles > 1) g = (g + 7) & ~7LL;                 // a pinned set starts at a multiple of 8
+        px.begin[k] = g; px.first[k] = (uint8_t)e; px.tiles[k] = (uint8_t)tiles;
+        long long most = 0;
+        for (int q = 0; q < tiles; ++q, ++e) {
+            const SpmvDeviceMatrix& m = *parts[e];
+            if (m.block_threads != threads || m.n_groups < 0) return hipErrorInvalidValue;
+            most = std::max<long long>(most, m.n_slices > 0 ? m.n_groups : 0);
+            lds = std::max(lds, ((size_t)m.lds_floats + (size_t)m.ytile_floats * (threads / 64)) * sizeof(float));
+        }
+        if (tiles == 1) g += most;
+        else { const int per = 8 / tiles; g += 8 * ((most + per - 1) / per); }
+    }
+    if (e != n) return hipErrorInvalidValue;
+    px.begin[n_items] = g;
+    if (g > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t err;
+        if ((err = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return err;
+        raised = true;
+    }
+    if (g > 0) hipLaunchKernelGGL(spmv_slices_multi_kernel, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_parts(float* y, const float* parts, int n_parts, int64_t part_stride, int32_t rows, int nv,
+                              int64_t y_stride, int64_t vec_stride, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_parts <= 0 || rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(spmv_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)nv), dim3(256), 0, stream,
+                       y, parts, n_parts, (long long)part_stride, rows, (long long)y_stride, (long long)vec_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_multi(const int32_t* rows, int n, const MultiMergeEntry* d_table, hipStream_t stream) {
+    (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
     if (n > kMultiMax) return hipErrorInvalidValue;
     MultiPrefix px{};
     px.n = n;
-    long long g = 0;
-    size_t lds = 0;
-    const int threads = parts[0]->block_threads;
-    for (int i = 0; i < n; ++i) {
-        const SpmvDeviceMatrix& m = *parts[i];
-        if (m.block_threads != threads || m.n_groups < 0) return hipErrorInvalidValue;
-        px.begin[i] = g; g += m.n_slices > 0 ? m.n_groups : 0;
-        lds = std::max(lds, ((size_t)m.lds_floats + (size_t)m.ytile_floats * (threads / 64)) * sizeof(float));
-    }
-    px.begin[n] = g;
-    if (g > 0x7fffffffLL) return hipErrorInvalidValue;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
-        raised = true;
-    }
-    if (g > 0) {
-        if (beta != 0.0f) hipLaunchKernelGGL(spmv_slices_multi_kernel<true>, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha, beta);
-        else hipLaunchKernelGGL(spmv_slices_multi_kernel<false>, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha, beta);
-    }
+    long long b = 0;
+    for (int i = 0; i < n; ++i) { px.begin[i] = b; b += (rows[i] + 255) / 256; }
+    px.begin[n] = b;
+    if (b > 0) hipLaunchKernelGGL(spmv_merge_multi_kernel, dim3((unsigned)b), dim3(256), 0, stream, d_table, px);
     return hipGetLastError();
 }
 

@@ -44,15 +44,20 @@ def prepared_tiles(info, r, c, v, rows, cols):
 
 
 def emulate_tiles(tiles, x, b, alpha, beta, rows, mode):
+    """Tile 0 computes alpha*A_0*x + beta*bias; every further column tile computes alpha*A_t*x into a partial vector
+    (its own cut rows fixed up there), and the merge pass adds the partial vectors to y in tile order."""
     ye = None
     for t, P in enumerate(tiles):
-        ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b if t == 0 else ye, alpha, beta if t == 0 else 1.0, rows, mode)
+        if t == 0:
+            ye = oracle.emu_spmv(P.words, P.hdr, P.fix, x, b, alpha, beta, rows, mode)
+        else:
+            ye = (ye + oracle.emu_spmv(P.words, P.hdr, P.fix, x, np.zeros(rows, np.float32), alpha, 0.0, rows, mode)).astype(np.float32)
     return ye
 
 
 def emulate_device(info, r, c, v, rows, cols, x, b, alpha, beta, carry=None):
     """The wavefront model applied the way the device runs the handle: one stream per column tile (tile 0
-    with beta*bias, later tiles accumulating in place), carry variant as reported by matrix_info (or `carry`:
+    with beta*bias, later tiles into partial vectors added afterwards), carry variant as reported by matrix_info (or `carry`:
     a batched pass always uses the fix-up variant, 0)."""
     return emulate_tiles(prepared_tiles(info, r, c, v, rows, cols), x, b, alpha, beta, rows,
                          info["carry_lookback"] if carry is None else carry)
