@@ -31,7 +31,7 @@ class MatrixInfo(C.Structure):
         ("device_bytes", C.c_int64), ("prep_seconds", C.c_double),
         ("block_threads", C.c_int32), ("group_slices", C.c_int32), ("lds_bytes", C.c_int32), ("col_tiles", C.c_int32),
         ("carry_lookback", C.c_int32), ("col_tile_width", C.c_int32),
-        ("col_tile_base", C.c_int32), ("reserved", C.c_int32),
+        ("col_tile_base", C.c_int32), ("compact_slices", C.c_int32),
     ]
 
 

@@ -43,11 +43,12 @@ struct Matrix {
         SliceStream st;                            // host side (released after upload)
         std::vector<FixEntry> fix_short, fix_long;
         LaunchPlan plan;
+        DeviceStream dstream;                      // the planned stream in its device layout (compact / wide groups)
         SpmvDeviceMatrix dev;                      // device side
     };
     std::vector<Part> parts;
     std::vector<float> dense_host;
-    int64_t n_slices = 0, n_elems = 0, n_split = 0;
+    int64_t n_slices = 0, n_elems = 0, n_split = 0, compact_slices = 0;
     int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
     bool l2_tiles = false;      // the column tiles gather x through L2 (L2-sized tiles): pinned to XCD subsets in a batch call
     float* d_dense = nullptr;
@@ -146,8 +147,8 @@ void free_batch_plans(hispmv_ctx* c) {
     c->batch_plans.clear();
 }
 
-int64_t sparse_device_bytes(const SliceStream& st) {
-    return (int64_t)st.words.size() * 8 + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
+int64_t sparse_device_bytes(const SliceStream& st, const DeviceStream& ds) {
+    return (int64_t)ds.bytes.size() + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
            (int64_t)st.n_slices * 12 + 8;
 }
 
@@ -221,6 +222,8 @@ int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
 void finish_part(Matrix::Part& p, int n_cus) {
     for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
     p.plan = make_plan(p.st, n_cus);     // also rewrites the column field of LDS-staged groups
+    p.dstream = pack_device_stream(p.st, p.plan);
+    p.st.words = std::vector<uint64_t>();   // the device layout replaces the host words
 }
 
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
@@ -303,7 +306,8 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
     csr = Csr{};
     for (auto& p : m->parts) {
         m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
-        m->device_bytes += sparse_device_bytes(p.st) + (int64_t)p.plan.groups.size() * 16 + (int64_t)p.plan.frags.size() * 16;
+        m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
+        m->compact_slices += p.dstream.compact_slices;
     }
     if (m->parts.size() > 1) m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of tiles t > 0
     m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
@@ -566,12 +570,12 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             m.d_dense = const_cast<float*>(d);
         } else {
             for (auto& p : m.parts) {
-                const uint64_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
-                const GroupDesc* dg = nullptr; const Frag* dfr = nullptr;
+                const uint8_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
+                const int32_t* dg = nullptr; const Frag* dfr = nullptr;
                 const int64_t ns = p.st.n_slices;
-                if ((rc = upload(c, m, p.plan.groups.data(), p.plan.groups.size(), &dg)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.dstream.groups.data(), p.dstream.groups.size(), &dg)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.plan.frags.data(), p.plan.frags.size(), &dfr)) != HISPMV_OK) return rc;
-                if ((rc = upload(c, m, p.st.words.data(), p.st.words.size(), &dw)) != HISPMV_OK) return rc;
+                if ((rc = upload(c, m, p.dstream.bytes.data(), p.dstream.bytes.size(), &dw)) != HISPMV_OK) return rc;
                 // device header: {row_base, chain_len, rows ending in the slice, 1 if some of its elements lie outside
                 // the group's x window} (the column window of a slice is only needed by the planner)
                 std::vector<SliceHdr>& hh = p.st.hdr;
@@ -637,7 +641,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // host copies are no longer needed
-        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; p.plan.frags = {}; }
+        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; p.plan.frags = {}; p.dstream = DeviceStream{}; }
         m.dense_host = {};
         m.loaded = true;
     }
@@ -924,7 +928,7 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->device_bytes = m.device_bytes; out->prep_seconds = m.prep_seconds;
     out->block_threads = m.plan_threads; out->group_slices = m.plan_group; out->lds_bytes = m.plan_lds * 4;
     out->col_tiles = (int32_t)m.parts.size();
-    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width; out->col_tile_base = m.col_tile_base; out->reserved = 0;
+    out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width; out->col_tile_base = m.col_tile_base; out->compact_slices = (int32_t)std::min<int64_t>(m.compact_slices, INT32_MAX);
     return HISPMV_OK;
 }
 

@@ -7,11 +7,11 @@
 namespace hispmv {
 
 struct SpmvDeviceMatrix {
-    const uint64_t* words = nullptr;    // n_slices * kSliceElems packed elements
+    const void* words = nullptr;        // the slices in their device layout (hispmv_format.h), group after group
     const int4* hdr = nullptr;          // n_slices x {row_base, chain_len, rows ending in the slice, 1 if elements lie outside the x window}
     const int4* fix_short = nullptr;    // {row, first_slice, len, 0}, len <= kFixShortMax
     const int4* fix_long = nullptr;     // same, len > kFixShortMax
-    const int4* groups = nullptr;       // n_groups x {frag_begin, frag_count, lds_floats, 0}: the x fragments a workgroup stages
+    const int4* groups = nullptr;       // n_groups x {frag_begin, frag_count, offset of the group's first slice / kSliceUnit, 1 = compact}
     const int4* frags = nullptr;        // {col_start, len, lds_off, 0}
     float* carry = nullptr;             // n_slices: partial sum each slice hands to the next
     int64_t n_groups = 0;
@@ -43,7 +43,7 @@ struct LookbackArgs {
 
 // Multi-matrix launch (hispmv_spmv_device_batch): device table entry per matrix part ...
 struct MultiEntry {
-    const uint64_t* words; const int4* hdr; const int4* groups; const int4* frags;
+    const void* words; const int4* hdr; const int4* groups; const int4* frags;
     const float* x; const float* bias; float* y; float* carry;
     long long n_slices;
     int32_t group_slices, lds_floats, ytile_floats, cols, rows;

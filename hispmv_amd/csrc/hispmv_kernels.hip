@@ -116,31 +116,115 @@ __device__ __forceinline__ float lookback_chain(const LookbackArgs& lb, lds_u64*
 // Slice kernel.  One workgroup owns a GROUP of consecutive slices (the analogue of a PE group fed by
 // one x window, LoadB base_functions.cpp:105-150); its wavefronts take the group's slices round-robin.
 //   group, once: the group's x FRAGMENTS (runs of the 64-byte blocks of x its slices touch, hispmv_plan.h) are
-//            staged into LDS with coalesced 16-byte loads; the words of such a group index that window.  A group
+//            staged into LDS with coalesced 16-byte loads; the metas of such a group index that window.  A group
 //            without fragments gathers x through L2; single elements outside the window do too (kGlobalColBit).
-//   slice:   8 x global_load_dwordx4 (non-temporal) bring the 8 KiB slice -- requested one iteration ahead;
-//            row ids from ballots; 16 gathers (ds_read_b32 or buffer loads) + the bias of the slice's rows;
-//            products; next slice requested; 8 steps of pair-combine + DPP segmented scan (totals in registers);
-//            row totals -> this wavefront's LDS tile -> coalesced y = alpha*total + beta*bias stores; the partial
-//            sum left open goes to carry[slice] (fix-up launch) or to the look-back mailbox/granule.
+//   slice:   structure of arrays, 4 steps of 256 elements, 4 consecutive elements per lane and step: per step one
+//            global_load_dwordx4 (values) + one dwordx2 (compact 16-bit metas: 6 bytes per element) or dwordx4 (wide
+//            metas), non-temporal, requested one iteration ahead; row ids from ballots; 16 gathers (ds_read_b32 or
+//            buffer loads) + the bias of the slice's rows; products; next slice requested; 4 steps of lane-local
+//            combine + DPP segmented scan (totals in registers); row totals -> this wavefront's LDS tile -> coalesced
+//            y = alpha*total + beta*bias stores; the partial sum left open goes to carry[slice] (fix-up launch) or to
+//            the look-back mailbox/granule.
 // ---------------------------------------------------------------------------
-// One 16-byte piece of the packed stream.  The stream is read exactly once per launch: the non-temporal
+// One 16-byte / 8-byte piece of the packed stream.  The stream is read exactly once per launch: the non-temporal
 // hint keeps it from evicting x, y and the fragment tables from L2 (measured: -5..8 % kernel time on
 // PFlow_742, soc-Pokec and mouse_gene).
+// Every pointer is cast to the GLOBAL address space first: the multi-matrix kernel takes its pointers from a table in
+// memory, where hipcc cannot tell global from LDS and would emit FLAT loads -- those count on lgkmcnt as well and return
+// out of order, so every wait for an LDS gather would also wait for the prefetch of the next slice.
+#define HISPMV_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ uint4 load_words(const uint4* p) {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const u4v v = __builtin_nontemporal_load((const u4v*)p);
+    const u4v v = __builtin_nontemporal_load((const HISPMV_GLOBAL u4v*)p);
     return uint4{v.x, v.y, v.z, v.w};
 }
+__device__ __forceinline__ uint2 load_words2(const uint2* p) {
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    const u2v v = __builtin_nontemporal_load((const HISPMV_GLOBAL u2v*)p);
+    return uint2{v.x, v.y};
+}
+__device__ __forceinline__ int4 load_int4(const int4* p) {
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    const i4v v = *(const HISPMV_GLOBAL i4v*)p;
+    return int4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ float4 load_float4(const float4* p) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = *(const HISPMV_GLOBAL f4v*)p;
+    return float4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store_float(float* p, float v) { *(HISPMV_GLOBAL float*)p = v; }
 
-// The work of one workgroup on group `group` of a matrix (the body of the slice kernels below).
-template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
-__device__ __forceinline__ void slices_body(
-    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+// A slice as it arrives: per step 4 values and 4 metas per lane (compact: 4 x u16 in a uint2; wide: 4 x u32).
+template <bool COMPACT> struct SliceRaw;
+template <> struct SliceRaw<true>  { uint4 v[kSliceSteps]; uint2 m[kSliceSteps]; };
+template <> struct SliceRaw<false> { uint4 v[kSliceSteps]; uint4 m[kSliceSteps]; };
+template <bool COMPACT>
+__device__ __forceinline__ void request_slice(SliceRaw<COMPACT>& s, const char* base, int lane) {
+    const uint4* pv = (const uint4*)base + lane;
+#pragma unroll
+    for (int j = 0; j < kSliceSteps; ++j) s.v[j] = load_words(pv + j * 64);
+    if constexpr (COMPACT) {
+        const uint2* pm = (const uint2*)(base + kSliceElems * 4) + lane;
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) s.m[j] = load_words2(pm + j * 64);
+    } else {
+        const uint4* pm = (const uint4*)(base + kSliceElems * 4) + lane;
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) s.m[j] = load_words(pm + j * 64);
+    }
+}
+// -> metas in wide form (rowEnd<<31 | window index or column), c[4*j + k] = element k of the lane in step j
+template <bool COMPACT>
+__device__ __forceinline__ void decode_metas(const SliceRaw<COMPACT>& s, unsigned (&c)[kSliceSteps * kLaneElems]) {
+    if constexpr (COMPACT) {
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            const unsigned a = s.m[j].x, b = s.m[j].y;
+            c[4 * j + 0] = ((a & 0x8000u) << 16) | (a & 0x7fffu);
+            c[4 * j + 1] = (a & 0x80000000u) | ((a >> 16) & 0x7fffu);
+            c[4 * j + 2] = ((b & 0x8000u) << 16) | (b & 0x7fffu);
+            c[4 * j + 3] = (b & 0x80000000u) | ((b >> 16) & 0x7fffu);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) { c[4 * j + 0] = s.m[j].x; c[4 * j + 1] = s.m[j].y; c[4 * j + 2] = s.m[j].z; c[4 * j + 3] = s.m[j].w; }
+    }
+}
+
+// PreAccumulator + row distribution network for one step of 256 elements: each lane combines its 4 products left to
+// right inside row segments, the open tails go through the DPP segmented scan, and every row end gets its total.
+//   p[k], e[k]: products and row-end flags of the lane's elements; carry_step: partial of the row left open by the
+//   previous step (in/out); t[k]: total of the row that ends at element k (meaningful where e[k]).
+__device__ __forceinline__ void scan_step(const float (&p)[kLaneElems], unsigned e, float& carry_step, float (&t)[kLaneElems]) {
+    const bool e0 = e & 1u, e1 = e & 2u, e2 = e & 4u, e3 = e & 8u;
+    const float s0 = p[0];
+    const float s1 = e0 ? p[1] : s0 + p[1];
+    const float s2 = e1 ? p[2] : s1 + p[2];
+    const float s3 = e2 ? p[3] : s2 + p[3];
+    // what this lane hands to its right neighbour, and whether it cuts the chain
+    float v = e3 ? 0.0f : s3;
+    int F = e ? 1 : 0;
+    seg_scan_wave(v, F);
+    v = F ? v : v + carry_step;
+    // incoming partial for this lane = inclusive value of the lane below (lane 0: previous step)
+    const float cin = i2f(__builtin_amdgcn_update_dpp(f2i(carry_step), f2i(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
+    carry_step = i2f(__builtin_amdgcn_readlane(f2i(v), 63));
+    t[0] = cin + s0;
+    t[1] = e0 ? s1 : cin + s1;
+    t[2] = (e0 | e1) ? s2 : cin + s2;
+    t[3] = (e0 | e1 | e2) ? s3 : cin + s3;
+}
+
+// The work of one workgroup on group `group` of a matrix (the body of the slice kernels below), for a group stored
+// COMPACT (6 B per element) or wide (8 B): two instantiations, chosen per group by slices_body.
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool COMPACT>
+__device__ __forceinline__ void slices_group(
+    const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags,
-    const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
+    const float* __restrict__ x, const float* bias, float* y,   // bias may alias y
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group) {
+    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group, int4 g) {
     // LDS: [x window: lds_floats][row totals of the slice in flight: ytile_floats per wavefront]
     extern __shared__ float xs[];
     // x, bias and y are reached through buffer descriptors: 32-bit byte offsets instead of 64-bit
@@ -151,34 +235,23 @@ __device__ __forceinline__ void slices_body(
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, rows * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, rows * 4, 0x00020000);
     constexpr unsigned kNoAccess = 0xffffffffu;
-    __shared__ long long s_group;
+    constexpr int kE = kSliceSteps * kLaneElems;     // elements of a slice per lane (16)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     float* const ytile = xs + (USE_LDS ? lds_floats : 0) + wave * ytile_floats;
     // look-back mailbox of the group: one {carry, launch tag} per slice, published by the wavefront that owns it
     lds_u64* const mbox = (lds_u64*)(xs + (USE_LDS ? lds_floats : 0) + (blockDim.x >> 6) * ytile_floats);
-    if (LOOKBACK) {
-        // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
-        // may have to wait for belongs to a workgroup that is already running or done -- the carry
-        // look-back below cannot deadlock whatever order the dispatcher picks.  The ticket counter is
-        // never reset: launch k consumes tickets [k*n_groups, (k+1)*n_groups).
-        // When the whole grid is co-resident (lb.use_ticket == 0, decided on the host from the launch
-        // plan) every workgroup is running anyway and blockIdx order needs no ticket.
-        if (lb.use_ticket) {
-            if (threadIdx.x == 0)
-                s_group = (long long)(__hip_atomic_fetch_add(lb.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - lb.ticket_base);
-            __syncthreads();
-            group = s_group;
-        }
-    }
-
     const long long first = group * group_slices;
     const long long last = (first + group_slices < n_slices) ? first + group_slices : n_slices;   // exclusive
+    // where the group's slices lie in the stream: the group table says so for staged plans; a plan without windows is
+    // all wide, slice after slice
+    constexpr int slice_bytes = COMPACT ? kCompactSliceBytes : kWideSliceBytes;
+    const char* const gbase = stream + (USE_LDS ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(g.z) * kSliceUnit
+                                                : (size_t)first * kWideSliceBytes);
 
     // MM2S_A, software-pipelined: the slice a wavefront works on was requested one iteration earlier
-    // (8 x global_load_dwordx4 = the whole 8 KiB, plus its header), so the HBM latency of slice k+1 hides
-    // behind the gathers, scans and stores of slice k.  The first request goes out BEFORE the x window is
-    // staged: it depends on nothing but the slice id.
+    // (the whole slice, plus its header), so the HBM latency of slice k+1 hides behind the gathers, scans
+    // and stores of slice k.  The first request goes out BEFORE the x window is staged.
     // Each workgroup walks its group from a different starting slice (rotation by a multiple of its id): workgroups
     // that all march through their groups from slice 0 at the same pace read addresses one group stride apart at
     // every moment, and some strides alias in the HBM channel hash -- PFlow_742 with 145 slices per workgroup ran 72
@@ -186,14 +259,12 @@ __device__ __forceinline__ void slices_body(
     const int n_here = (int)(last > first ? last - first : 0);
     const int rot = (LOOKBACK || n_here == 0) ? 0 : (int)((unsigned long long)group * 29ull % (unsigned)n_here);
     int k_slice = wave;                                         // position in the group's rotated order
-    long long slice = k_slice < n_here ? first + (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : last;
-    uint4 w[kSliceSteps];
+    int local = k_slice < n_here ? (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : n_here;
+    SliceRaw<COMPACT> w;
     int4 h = int4{0, 0, 0, 0};
-    if (slice < last) {
-        const uint4* p = words + slice * (kSliceElems / 2) + lane;
-#pragma unroll
-        for (int j = 0; j < kSliceSteps; ++j) w[j] = load_words(p + j * 64);
-        h = hdr[slice];
+    if (local < n_here) {
+        request_slice<COMPACT>(w, gbase + (size_t)local * slice_bytes, lane);
+        h = load_int4(hdr + first + local);
     }
 
     if (LOOKBACK) {
@@ -201,24 +272,23 @@ __device__ __forceinline__ void slices_body(
         if (!USE_LDS) __syncthreads();
     }
     // LoadB: stage the x fragments of this group (runs of 64-byte blocks its slices touch) into LDS; the
-    // words of a staged group already carry the index into this window instead of the column.
+    // metas of a staged group already carry the index into this window instead of the column.
     bool in_lds = false;
     if (USE_LDS) {
-        const int4 g = groups[group];
         in_lds = g.y > 0;                    // workgroup-uniform; 0 fragments = this group gathers through L2
         for (int f = wave; f < g.y; f += n_waves) {
-            const int4 fr = frags[g.x + f];  // {col_start, len, lds_off}: multiples of 16 floats
+            const int4 fr = load_int4(frags + g.x + f);  // {col_start, len, lds_off}: multiples of 16 floats
             const float4* src = (const float4*)(x + fr.x);
             float4* dst = (float4*)(xs + fr.z);
             for (int i = lane; i < (fr.y >> 2); i += 64) {
                 // the last block of x may reach past cols: read it element-wise
-                if (fr.x + 4 * i + 3 < cols) dst[i] = src[i];
-                else {
-                    float4 v = float4{0.f, 0.f, 0.f, 0.f};
-                    if (fr.x + 4 * i + 0 < cols) v.x = x[fr.x + 4 * i + 0];
-                    if (fr.x + 4 * i + 1 < cols) v.y = x[fr.x + 4 * i + 1];
-                    if (fr.x + 4 * i + 2 < cols) v.z = x[fr.x + 4 * i + 2];
-                    dst[i] = v;
+                if (fr.x + 4 * i + 3 < cols) dst[i] = load_float4(src + i);
+                else {      // (through the buffer descriptor: out-of-range reads return 0, no private array)
+                    const unsigned o = (unsigned)(fr.x + 4 * i) << 2;
+                    const float a0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+                    const float a1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, o + 4, 0, 0));
+                    const float a2 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, o + 8, 0, 0));
+                    dst[i] = float4{a0, a1, a2, 0.f};
                 }
             }
         }
@@ -234,13 +304,12 @@ __device__ __forceinline__ void slices_body(
     int def_row = 0, def_len = 0, pend_row = 0, pend_len = 0;
     float def_t = 0.0f, def_b = 0.0f, pend_t = 0.0f, pend_b = 0.0f;
 
-    while (slice < last) {
+    while (local < n_here) {
         int row = __builtin_amdgcn_readfirstlane(h.x);
         const int row_first = row;                                   // first row that ends in this slice
         const int chain_len = __builtin_amdgcn_readfirstlane(h.y);   // >0: that row began chain_len slices earlier
-
         const int n_rows = __builtin_amdgcn_readfirstlane(h.z);      // rows that end in this slice
-        const bool spills = USE_LDS && __builtin_amdgcn_readfirstlane(h.w) != 0;   // elements outside the x window
+        const bool spills = USE_LDS && __builtin_amdgcn_readfirstlane(h.w) != 0;   // elements outside the x window (wide groups only)
         // Compute_C operand: the slice's rows are consecutive, so bias is read with coalesced loads that leave
         // together with the x gathers (first 128 rows here, the rest in the epilogue loop).
         float bpre0 = 0.0f, bpre1 = 0.0f;
@@ -248,57 +317,58 @@ __device__ __forceinline__ void slices_body(
             bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (unsigned)(row_first + lane) << 2 : kNoAccess, 0, 0));
             bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (unsigned)(row_first + lane + 64) << 2 : kNoAccess, 0, 0));
         }
-        // Local row ids of every row end (ballot + mbcnt prefix counts; no per-element row field).
+        unsigned c[kE];
+        decode_metas<COMPACT>(w, c);
+        // Local row ids of every row end (ballots + mbcnt prefix counts; no per-element row field): r0[j] = row of
+        // the lane's first row end in step j, the lane's further ends follow it.
         int r0[kSliceSteps];
+        unsigned ends = 0;     // bit 4j + k = element k of step j ends its row
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64((w[j].y & kRowEndBit) != 0);
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64((w[j].w & kRowEndBit) != 0);
-            r0[j] = row + lanes_below(m0) + lanes_below(m1);
-            row += __builtin_popcountll(m0) + __builtin_popcountll(m1);
+            int below = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < kLaneElems; ++k) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64((c[4 * j + k] & kRowEndBit) != 0);
+                below += lanes_below(m);
+                total += __builtin_popcountll(m);
+                ends |= (c[4 * j + k] >> 31) << (4 * j + k);
+            }
+            r0[j] = row + below;
+            row += total;
         }
 
-        // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather) and, for Compute_C, bias[row]
-        float x0[kSliceSteps], x1[kSliceSteps];
+        // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather)
+        float xv[kE];
         if (USE_LDS && in_lds && !spills) {
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                x0[j] = xs[w[j].y & ~kRowEndBit];
-                x1[j] = xs[w[j].w & ~kRowEndBit];
-            }
+            for (int i = 0; i < kE; ++i) xv[i] = xs[c[i] & ~kRowEndBit];
         } else if (USE_LDS && in_lds) {
             // window of the group's most used blocks: the elements outside it (kGlobalColBit) gather through L2 --
             // lanes inside the window give the buffer load an out-of-range offset (no access, returns 0)
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
-                x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c0 & kGlobalColBit) ? c0 << 2 : kNoAccess, 0, 0));
-                x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c1 & kGlobalColBit) ? c1 << 2 : kNoAccess, 0, 0));
+            for (int i = 0; i < kE; ++i) {
+                const unsigned ci = c[i] & ~kRowEndBit;
+                xv[i] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (ci & kGlobalColBit) ? ci << 2 : kNoAccess, 0, 0));
             }
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
-                const float l0 = xs[(c0 & kGlobalColBit) ? 0u : c0], l1 = xs[(c1 & kGlobalColBit) ? 0u : c1];
-                x0[j] = (c0 & kGlobalColBit) ? x0[j] : l0;
-                x1[j] = (c1 & kGlobalColBit) ? x1[j] : l1;
+            for (int i = 0; i < kE; ++i) {
+                const unsigned ci = c[i] & ~kRowEndBit;
+                const float l = xs[(ci & kGlobalColBit) ? 0u : ci];
+                xv[i] = (ci & kGlobalColBit) ? xv[i] : l;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w[j].y & ~kRowEndBit) << 2, 0, 0));
-                x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w[j].w & ~kRowEndBit) << 2, 0, 0));
-            }
+            for (int i = 0; i < kE; ++i) xv[i] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c[i] & ~kRowEndBit) << 2, 0, 0));
         }
-        // ComputeAB: val * x[col]; keep only the row-end flags of this slice, then request the next slice
-        // into the same registers (issued AFTER this slice's gathers so that waiting for the gathers does not
-        // wait for the prefetch: vmcnt retires in issue order).
-        float p0[kSliceSteps], p1[kSliceSteps];
-        unsigned ends = 0;     // bit 2j = e0 of step j, bit 2j+1 = e1
+        // ComputeAB: val * x[col]; then request the next slice into the same registers (issued AFTER this slice's
+        // gathers so that waiting for the gathers does not wait for the prefetch: vmcnt retires in issue order).
+        float p[kE];
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            p0[j] = i2f((int)w[j].x) * x0[j];
-            p1[j] = i2f((int)w[j].z) * x1[j];
-            ends |= ((w[j].y >> 31) << (2 * j)) | ((w[j].w >> 31) << (2 * j + 1));
+            p[4 * j + 0] = i2f((int)w.v[j].x) * xv[4 * j + 0];
+            p[4 * j + 1] = i2f((int)w.v[j].y) * xv[4 * j + 1];
+            p[4 * j + 2] = i2f((int)w.v[j].z) * xv[4 * j + 2];
+            p[4 * j + 3] = i2f((int)w.v[j].w) * xv[4 * j + 3];
         }
         // hipcc would hoist the prefetch above the products (its results land in fresh registers); the waits for the
         // gathers, placed after the point where the three gather paths merge, then count conservatively and wait for
@@ -307,36 +377,26 @@ __device__ __forceinline__ void slices_body(
         // and lose 0.4 us to the barrier).
         if (!LOOKBACK) {
 #pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) asm volatile("" : "+v"(p0[j]), "+v"(p1[j]));
+            for (int i = 0; i < kE; ++i) asm volatile("" : "+v"(p[i]));
             asm volatile("" ::: "memory");
         }
-        const long long cur = slice;
+        const long long cur = first + local;
         k_slice += n_waves;
-        slice = k_slice < n_here ? first + (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : last;
-        if (slice < last) {
-            const uint4* p = words + slice * (kSliceElems / 2) + lane;
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) w[j] = load_words(p + j * 64);
-            h = hdr[slice];
+        local = k_slice < n_here ? (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : n_here;
+        if (local < n_here) {
+            request_slice<COMPACT>(w, gbase + (size_t)local * slice_bytes, lane);
+            h = load_int4(hdr + first + local);
         }
 
-        // PreAccumulator + row distribution network: segmented scan per 128-element step
-        float t0[kSliceSteps], t1[kSliceSteps];
+        // PreAccumulator + row distribution network: lane-local combine + segmented scan per 256-element step
+        float t[kE];
         float carry_step = 0.0f;       // partial sum of the row left open by the previous step
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            const bool e0 = (ends >> (2 * j)) & 1u;
-            const bool e1 = (ends >> (2 * j + 1)) & 1u;
-            // what this lane hands to its right neighbour, and whether it cuts the chain
-            float v = e1 ? 0.0f : (e0 ? p1[j] : p0[j] + p1[j]);
-            int F = (e0 | e1) ? 1 : 0;
-            seg_scan_wave(v, F);
-            v = F ? v : v + carry_step;
-            // incoming partial for this lane = inclusive value of the lane below (lane 0: previous step)
-            const float cin = i2f(__builtin_amdgcn_update_dpp(f2i(carry_step), f2i(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
-            carry_step = i2f(__builtin_amdgcn_readlane(f2i(v), 63));
-            t0[j] = cin + p0[j];
-            t1[j] = e0 ? p1[j] : cin + (p0[j] + p1[j]);
+            const float pj[kLaneElems] = {p[4 * j], p[4 * j + 1], p[4 * j + 2], p[4 * j + 3]};
+            float tj[kLaneElems];
+            scan_step(pj, (ends >> (4 * j)) & 0xfu, carry_step, tj);
+            t[4 * j] = tj[0]; t[4 * j + 1] = tj[1]; t[4 * j + 2] = tj[2]; t[4 * j + 3] = tj[3];
         }
 
         bool deferred = false, rolling = false;
@@ -356,8 +416,8 @@ __device__ __forceinline__ void slices_body(
             if (pend_slice >= 0) {
                 const float chain = lookback_chain(lb, mbox, first, pend_slice, pend_len, lane);
                 if (lane == 0) {
-                    const float t = pend_t + chain;
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * t + beta * pend_b : alpha * t), ry,
+                    const float tt = pend_t + chain;
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * tt + beta * pend_b : alpha * tt), ry,
                                                           (unsigned)pend_row << 2, 0, 0);
                 }
                 pend_slice = -1;
@@ -370,52 +430,91 @@ __device__ __forceinline__ void slices_body(
 
         // AccumBuffer -> Compute_C: the row totals go through this wavefront's LDS tile (one ds_write per row
         // end) and leave as COALESCED y = alpha*total + beta*bias stores: ceil(n_rows/64) load/store pairs per
-        // slice instead of 32 mostly-empty predicated ones (the output phase cost 25-30 % that way).
+        // slice instead of mostly-empty predicated ones (the output phase cost 25-30 % that way).
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
-            if (e0) ytile[r0[j] - row_first] = t0[j];
-            if (e1) ytile[r0[j] - row_first + (e0 ? 1 : 0)] = t1[j];
+            const unsigned e = (ends >> (4 * j)) & 0xfu;
+            int pos = r0[j] - row_first;
+#pragma unroll
+            for (int k = 0; k < kLaneElems; ++k) {
+                if (e & (1u << k)) ytile[pos] = t[4 * j + k];
+                pos += (e >> k) & 1u;
+            }
         }
         const bool held = LOOKBACK && (deferred || rolling);   // the slice's first row is stored later, with its chain
         for (int i = lane; i < n_rows; i += 64) {
-            const float t = ytile[i];
+            const float tt = ytile[i];
             const unsigned dst = (held && i == 0) ? kNoAccess : (unsigned)(row_first + i) << 2;
             if (HAS_BETA) {
                 const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
                               : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(row_first + i) << 2, 0, 0));
-                if (LOOKBACK && deferred && i == 0) { def_t = t; def_b = b; }
-                if (LOOKBACK && rolling && i == 0) { pend_t = t; pend_b = b; }
-                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, dst, 0, 0);
+                if (LOOKBACK && deferred && i == 0) { def_t = tt; def_b = b; }
+                if (LOOKBACK && rolling && i == 0) { pend_t = tt; pend_b = b; }
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * tt + beta * b), ry, dst, 0, 0);
             } else {
-                if (LOOKBACK && deferred && i == 0) def_t = t;
-                if (LOOKBACK && rolling && i == 0) pend_t = t;
-                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, dst, 0, 0);
+                if (LOOKBACK && deferred && i == 0) def_t = tt;
+                if (LOOKBACK && rolling && i == 0) pend_t = tt;
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * tt), ry, dst, 0, 0);
             }
         }
-        if (!LOOKBACK && lane == 0) carry[cur] = carry_step;
+        if (!LOOKBACK && lane == 0) store_float(carry + cur, carry_step);
     }
     if (LOOKBACK && pend_slice >= 0) {    // the cut row of this wavefront's last slice
         const float chain = lookback_chain(lb, mbox, first, pend_slice, pend_len, lane);
         if (lane == 0) {
-            const float t = pend_t + chain;
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * t + beta * pend_b : alpha * t), ry,
+            const float tt = pend_t + chain;
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * tt + beta * pend_b : alpha * tt), ry,
                                                   (unsigned)pend_row << 2, 0, 0);
         }
     }
     if (LOOKBACK && def_slice >= 0) {     // wave-uniform: the row that crosses into this group from the previous one
         const float chain = lookback_chain(lb, mbox, first, def_slice, def_len, lane);
         if (lane == 0) {
-            const float t = def_t + chain;
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * t + beta * def_b : alpha * t), ry,
+            const float tt = def_t + chain;
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * tt + beta * def_b : alpha * tt), ry,
                                                   (unsigned)def_row << 2, 0, 0);
         }
     }
 }
 
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
+__device__ __forceinline__ void slices_body(
+    const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
+    float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
+    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group) {
+    __shared__ long long s_group;
+    if (LOOKBACK) {
+        // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
+        // may have to wait for belongs to a workgroup that is already running or done -- the carry
+        // look-back cannot deadlock whatever order the dispatcher picks.  The ticket counter is
+        // never reset: launch k consumes tickets [k*n_groups, (k+1)*n_groups).
+        // When the whole grid is co-resident (lb.use_ticket == 0, decided on the host from the launch
+        // plan) every workgroup is running anyway and blockIdx order needs no ticket.
+        if (lb.use_ticket) {
+            if (threadIdx.x == 0)
+                s_group = (long long)(__hip_atomic_fetch_add(lb.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - lb.ticket_base);
+            __syncthreads();
+            group = s_group;
+        }
+    }
+    if constexpr (USE_LDS) {
+        const int4 g = load_int4(groups + group);     // {first fragment, fragments, offset of the group's slices, compact}
+        if (__builtin_amdgcn_readfirstlane(g.w) != 0)
+            slices_group<HAS_BETA, true, LOOKBACK, true>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+                                                         lds_floats, ytile_floats, cols, rows, lb, group, g);
+        else
+            slices_group<HAS_BETA, true, LOOKBACK, false>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+                                                          lds_floats, ytile_floats, cols, rows, lb, group, g);
+    } else {
+        slices_group<HAS_BETA, false, LOOKBACK, false>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+                                                       lds_floats, ytile_floats, cols, rows, lb, group, int4{0, 0, 0, 0});
+    }
+}
+
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
 __global__ __launch_bounds__(1024) void spmv_slices_kernel(
-    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const char* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
     int lds_floats, int ytile_floats, int cols, int rows, LookbackArgs lb) {
@@ -448,10 +547,10 @@ __global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntr
     // beta is per entry: the first column tile of a matrix applies beta*bias, its other tiles write alpha*A_t*x into the
     // handle's partial vectors (no bias read) -- both kinds share the grid, a workgroup runs one of the two bodies
     if (t.beta != 0.0f)
-        slices_body<true, true, false>((const uint4*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, t.beta,
+        slices_body<true, true, false>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, t.beta,
                                        t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
     else
-        slices_body<false, true, false>((const uint4*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, alpha, 0.0f,
+        slices_body<false, true, false>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, alpha, 0.0f,
                                         t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
 }
 
@@ -504,52 +603,54 @@ __global__ __launch_bounds__(256) void spmv_merge_multi_kernel(const MultiMergeE
 // slice is requested after the last vector's products.  The x windows of the NV vectors sit side by side in LDS.
 // Host guarantees: cols % 4 == 0 when USE_LDS, cols*NV < 2^30, rows*NV < 2^30, NV*lds_floats + tiles fit LDS.
 // ---------------------------------------------------------------------------
-template <bool HAS_BETA, bool USE_LDS, int NV>
-__global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
-    const uint4* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+template <bool HAS_BETA, bool USE_LDS, int NV, bool COMPACT>
+__device__ __forceinline__ void batched_group(
+    const char* __restrict__ stream, const int4* __restrict__ hdr,
     const int4* __restrict__ frags,
-    const float* __restrict__ x, const float* bias, float* y,   // bias may alias y (column tiles t > 0)
+    const float* __restrict__ x, const float* bias, float* y,   // bias may alias y
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int ytile_floats, int cols, int rows, int bias_stride) {
+    int lds_floats, int ytile_floats, int cols, int rows, int bias_stride, int4 g) {
     extern __shared__ float xs[];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, cols * NV * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, (bias_stride ? rows * NV : rows) * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, rows * NV * 4, 0x00020000);
     constexpr unsigned kNoAccess = 0xffffffffu;
+    constexpr int kE = kSliceSteps * kLaneElems;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     float* const ytile = xs + (USE_LDS ? NV * lds_floats : 0) + wave * ytile_floats;
     const long long group = blockIdx.x;
     const long long first = group * group_slices;
     const long long last = (first + group_slices < n_slices) ? first + group_slices : n_slices;   // exclusive
+    constexpr int slice_bytes = COMPACT ? kCompactSliceBytes : kWideSliceBytes;
+    const char* const gbase = stream + (USE_LDS ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(g.z) * kSliceUnit
+                                                : (size_t)first * kWideSliceBytes);
 
     long long slice = first + wave;
-    uint4 w[kSliceSteps];
+    SliceRaw<COMPACT> w;
     int4 h = int4{0, 0, 0, 0};
     if (slice < last) {
-        const uint4* p = words + slice * (kSliceElems / 2) + lane;
-#pragma unroll
-        for (int j = 0; j < kSliceSteps; ++j) w[j] = load_words(p + j * 64);
-        h = hdr[slice];
+        request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
+        h = load_int4(hdr + slice);
     }
     bool in_lds = false;
     if (USE_LDS) {
-        const int4 g = groups[group];
         in_lds = g.y > 0;
         for (int v = 0; v < NV; ++v) {
             const float* xv = x + (size_t)v * cols;
             for (int f = wave; f < g.y; f += n_waves) {
-                const int4 fr = frags[g.x + f];
+                const int4 fr = load_int4(frags + g.x + f);
                 const float4* src = (const float4*)(xv + fr.x);
                 float4* dst = (float4*)(xs + v * lds_floats + fr.z);
                 for (int i = lane; i < (fr.y >> 2); i += 64) {
-                    if (fr.x + 4 * i + 3 < cols) dst[i] = src[i];
-                    else {
-                        float4 q = float4{0.f, 0.f, 0.f, 0.f};
-                        if (fr.x + 4 * i + 0 < cols) q.x = xv[fr.x + 4 * i + 0];
-                        if (fr.x + 4 * i + 1 < cols) q.y = xv[fr.x + 4 * i + 1];
-                        if (fr.x + 4 * i + 2 < cols) q.z = xv[fr.x + 4 * i + 2];
-                        dst[i] = q;
+                    if (fr.x + 4 * i + 3 < cols) dst[i] = load_float4(src + i);
+                    else {   // the last block of a vector may reach past its end: element-wise, zero beyond cols
+                        const int c0 = fr.x + 4 * i;
+                        const HISPMV_GLOBAL float* xg1 = (const HISPMV_GLOBAL float*)xv;
+                        const float a0 = c0 + 0 < cols ? xg1[c0 + 0] : 0.f;
+                        const float a1 = c0 + 1 < cols ? xg1[c0 + 1] : 0.f;
+                        const float a2 = c0 + 2 < cols ? xg1[c0 + 2] : 0.f;
+                        dst[i] = float4{a0, a1, a2, 0.f};
                     }
                 }
             }
@@ -562,15 +663,28 @@ __global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
         const int row_first = row;
         const int n_rows = __builtin_amdgcn_readfirstlane(h.z);
         const bool spills = USE_LDS && __builtin_amdgcn_readfirstlane(h.w) != 0;
+        unsigned c[kE];
+        decode_metas<COMPACT>(w, c);
+        float val[kE];
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            val[4 * j + 0] = i2f((int)w.v[j].x); val[4 * j + 1] = i2f((int)w.v[j].y);
+            val[4 * j + 2] = i2f((int)w.v[j].z); val[4 * j + 3] = i2f((int)w.v[j].w);
+        }
         int r0[kSliceSteps];
         unsigned ends = 0;
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64((w[j].y & kRowEndBit) != 0);
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64((w[j].w & kRowEndBit) != 0);
-            r0[j] = row + lanes_below(m0) + lanes_below(m1);
-            row += __builtin_popcountll(m0) + __builtin_popcountll(m1);
-            ends |= ((w[j].y >> 31) << (2 * j)) | ((w[j].w >> 31) << (2 * j + 1));
+            int below = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < kLaneElems; ++k) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64((c[4 * j + k] & kRowEndBit) != 0);
+                below += lanes_below(m);
+                total += __builtin_popcountll(m);
+                ends |= (c[4 * j + k] >> 31) << (4 * j + k);
+            }
+            r0[j] = row + below;
+            row += total;
         }
         const long long cur = slice;
 
@@ -583,83 +697,87 @@ __global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
                 bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (boff + row_first + lane) << 2 : kNoAccess, 0, 0));
                 bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (boff + row_first + lane + 64) << 2 : kNoAccess, 0, 0));
             }
-            float x0[kSliceSteps], x1[kSliceSteps];
+            float xg[kE];
             const float* xw = xs + v * lds_floats;
             if (USE_LDS && in_lds && !spills) {
 #pragma unroll
-                for (int j = 0; j < kSliceSteps; ++j) {
-                    x0[j] = xw[w[j].y & ~kRowEndBit];
-                    x1[j] = xw[w[j].w & ~kRowEndBit];
-                }
+                for (int i = 0; i < kE; ++i) xg[i] = xw[c[i] & ~kRowEndBit];
             } else if (USE_LDS && in_lds) {
 #pragma unroll
-                for (int j = 0; j < kSliceSteps; ++j) {
-                    const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
-                    x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c0 & kGlobalColBit) ? ((c0 & ~kGlobalColBit) + xoff) << 2 : kNoAccess, 0, 0));
-                    x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (c1 & kGlobalColBit) ? ((c1 & ~kGlobalColBit) + xoff) << 2 : kNoAccess, 0, 0));
+                for (int i = 0; i < kE; ++i) {
+                    const unsigned ci = c[i] & ~kRowEndBit;
+                    xg[i] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (ci & kGlobalColBit) ? ((ci & ~kGlobalColBit) + xoff) << 2 : kNoAccess, 0, 0));
                 }
 #pragma unroll
-                for (int j = 0; j < kSliceSteps; ++j) {
-                    const unsigned c0 = w[j].y & ~kRowEndBit, c1 = w[j].w & ~kRowEndBit;
-                    const float l0 = xw[(c0 & kGlobalColBit) ? 0u : c0], l1 = xw[(c1 & kGlobalColBit) ? 0u : c1];
-                    x0[j] = (c0 & kGlobalColBit) ? x0[j] : l0;
-                    x1[j] = (c1 & kGlobalColBit) ? x1[j] : l1;
+                for (int i = 0; i < kE; ++i) {
+                    const unsigned ci = c[i] & ~kRowEndBit;
+                    const float l = xw[(ci & kGlobalColBit) ? 0u : ci];
+                    xg[i] = (ci & kGlobalColBit) ? xg[i] : l;
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < kSliceSteps; ++j) {
-                    x0[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, ((w[j].y & ~kRowEndBit) + xoff) << 2, 0, 0));
-                    x1[j] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, ((w[j].w & ~kRowEndBit) + xoff) << 2, 0, 0));
-                }
+                for (int i = 0; i < kE; ++i) xg[i] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, ((c[i] & ~kRowEndBit) + xoff) << 2, 0, 0));
             }
-            float p0[kSliceSteps], p1[kSliceSteps];
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                p0[j] = i2f((int)w[j].x) * x0[j];
-                p1[j] = i2f((int)w[j].z) * x1[j];
-            }
-            if (v == NV - 1) {          // the words are no longer needed: request this wavefront's next slice
+            if (v == NV - 1) {
+                // the slice's values and metas live in val[] / c[]: request this wavefront's next slice behind the last
+                // vector's gathers (vmcnt retires in issue order: waiting for the gathers must not wait for the prefetch)
                 slice += n_waves;
                 if (slice < last) {
-                    const uint4* p = words + slice * (kSliceElems / 2) + lane;
-#pragma unroll
-                    for (int j = 0; j < kSliceSteps; ++j) w[j] = load_words(p + j * 64);
-                    h = hdr[slice];
+                    request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
+                    h = load_int4(hdr + slice);
                 }
             }
-            float t0[kSliceSteps], t1[kSliceSteps];
+            float t[kE];
             float carry_step = 0.0f;
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (ends >> (2 * j)) & 1u;
-                const bool e1 = (ends >> (2 * j + 1)) & 1u;
-                float q = e1 ? 0.0f : (e0 ? p1[j] : p0[j] + p1[j]);
-                int F = (e0 | e1) ? 1 : 0;
-                seg_scan_wave(q, F);
-                q = F ? q : q + carry_step;
-                const float cin = i2f(__builtin_amdgcn_update_dpp(f2i(carry_step), f2i(q), 0x138, 0xf, 0xf, false));  // wave_shr:1
-                carry_step = i2f(__builtin_amdgcn_readlane(f2i(q), 63));
-                t0[j] = cin + p0[j];
-                t1[j] = e0 ? p1[j] : cin + (p0[j] + p1[j]);
+                const float pj[kLaneElems] = {val[4 * j] * xg[4 * j], val[4 * j + 1] * xg[4 * j + 1], val[4 * j + 2] * xg[4 * j + 2], val[4 * j + 3] * xg[4 * j + 3]};
+                float tj[kLaneElems];
+                scan_step(pj, (ends >> (4 * j)) & 0xfu, carry_step, tj);
+                t[4 * j] = tj[0]; t[4 * j + 1] = tj[1]; t[4 * j + 2] = tj[2]; t[4 * j + 3] = tj[3];
             }
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                const bool e0 = (ends >> (2 * j)) & 1u, e1 = (ends >> (2 * j + 1)) & 1u;
-                if (e0) ytile[r0[j] - row_first] = t0[j];
-                if (e1) ytile[r0[j] - row_first + (e0 ? 1 : 0)] = t1[j];
+                const unsigned e = (ends >> (4 * j)) & 0xfu;
+                int pos = r0[j] - row_first;
+#pragma unroll
+                for (int k = 0; k < kLaneElems; ++k) {
+                    if (e & (1u << k)) ytile[pos] = t[4 * j + k];
+                    pos += (e >> k) & 1u;
+                }
             }
             for (int i = lane; i < n_rows; i += 64) {
-                const float t = ytile[i];
+                const float tt = ytile[i];
                 if (HAS_BETA) {
                     const float b = (i < 64) ? bpre0 : (i < 128) ? bpre1
                                   : i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, (boff + row_first + i) << 2, 0, 0));
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t + beta * b), ry, (yoff + row_first + i) << 2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * tt + beta * b), ry, (yoff + row_first + i) << 2, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * t), ry, (yoff + row_first + i) << 2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * tt), ry, (yoff + row_first + i) << 2, 0, 0);
                 }
             }
-            if (lane == 0) carry[(long long)v * n_slices + cur] = carry_step;
+            if (lane == 0) store_float(carry + (long long)v * n_slices + cur, carry_step);
         }
+    }
+}
+
+template <bool HAS_BETA, bool USE_LDS, int NV>
+__global__ __launch_bounds__(1024) void spmv_slices_batched_kernel(
+    const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
+    float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
+    int lds_floats, int ytile_floats, int cols, int rows, int bias_stride) {
+    if constexpr (USE_LDS) {
+        const int4 g = load_int4(groups + blockIdx.x);
+        if (__builtin_amdgcn_readfirstlane(g.w) != 0)
+            batched_group<HAS_BETA, true, NV, true>(stream, hdr, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices, lds_floats,
+                                                    ytile_floats, cols, rows, bias_stride, g);
+        else
+            batched_group<HAS_BETA, true, NV, false>(stream, hdr, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices, lds_floats,
+                                                     ytile_floats, cols, rows, bias_stride, g);
+    } else {
+        batched_group<HAS_BETA, false, NV, false>(stream, hdr, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices, lds_floats,
+                                                  ytile_floats, cols, rows, bias_stride, int4{0, 0, 0, 0});
     }
 }
 
@@ -701,7 +819,7 @@ static void launch_slices(const SpmvDeviceMatrix& m, const LookbackArgs& lb, con
     const size_t lds = ((USE_LDS ? (size_t)m.lds_floats : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float) +
                        (LOOKBACK ? (size_t)m.group_slices * 8 : 0);
     hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS, LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
-                       (const uint4*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
+                       (const char*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
                        (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, lb);
 }
 
@@ -767,7 +885,7 @@ static hipError_t launch_batched(const SpmvDeviceMatrix& m, const float* x, cons
         raised = true;
     }
     hipLaunchKernelGGL((spmv_slices_batched_kernel<HAS_BETA, USE_LDS, NV>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
-                       (const uint4*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
+                       (const char*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
                        (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, bias_stride);
     return hipGetLastError();
 }

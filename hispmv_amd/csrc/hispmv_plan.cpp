@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 
 namespace hispmv {
 
@@ -232,6 +233,47 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
     best.lds_floats = (max_lds + 3) & ~3;
     if (best.lds_floats == 0) best.lds_floats = kFragBlock;   // a plan with a window never reports 0
     return best;
+}
+
+DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan) {
+    DeviceStream d;
+    const int64_t n = st.n_slices, G = plan.group_slices;
+    const int64_t ng = std::max<int64_t>((n + G - 1) / G, 1);
+    d.groups.assign((size_t)ng * 4, 0);
+    std::vector<int64_t> off((size_t)ng + 1, 0);
+    std::vector<uint8_t> compact((size_t)ng, 0);
+    for (int64_t g = 0; g < ng; ++g) {
+        const GroupDesc gd = (size_t)g < plan.groups.size() ? plan.groups[(size_t)g] : GroupDesc{0, 0, 0, 0};
+        const int64_t s0 = g * G, s1 = std::min(n, s0 + G);
+        compact[(size_t)g] = gd.frag_count > 0 && gd.n_global == 0 && gd.lds_floats <= kCompactMaxIndex;
+        off[(size_t)g + 1] = off[(size_t)g] + std::max<int64_t>(s1 - s0, 0) * (compact[(size_t)g] ? kCompactSliceBytes : kWideSliceBytes);
+        d.groups[(size_t)g * 4 + 0] = gd.frag_begin; d.groups[(size_t)g * 4 + 1] = gd.frag_count;
+        d.groups[(size_t)g * 4 + 2] = (int32_t)(off[(size_t)g] / kSliceUnit); d.groups[(size_t)g * 4 + 3] = compact[(size_t)g];
+        if (compact[(size_t)g]) d.compact_slices += std::max<int64_t>(s1 - s0, 0);
+    }
+    if (off[(size_t)ng] / kSliceUnit > INT32_MAX) throw std::length_error("stream larger than 4 TiB");
+    d.bytes.resize((size_t)off[(size_t)ng]);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t g = 0; g < ng; ++g) {
+        const int64_t s0 = g * G, s1 = std::min(n, s0 + G);
+        for (int64_t sl = s0; sl < s1; ++sl) {
+            const uint64_t* w = st.words.data() + sl * kSliceElems;
+            uint8_t* base = d.bytes.data() + off[(size_t)g] + (sl - s0) * (compact[(size_t)g] ? kCompactSliceBytes : kWideSliceBytes);
+            uint32_t* vals = (uint32_t*)base;
+            for (int i = 0; i < kSliceElems; ++i) vals[i] = (uint32_t)w[i];
+            if (compact[(size_t)g]) {
+                uint16_t* meta = (uint16_t*)(base + kSliceElems * 4);
+                for (int i = 0; i < kSliceElems; ++i) {
+                    const uint32_t m = (uint32_t)(w[i] >> 32);
+                    meta[i] = (uint16_t)((m & 0x7fffu) | ((m & kRowEndBit) ? kCompactEndBit : 0u));
+                }
+            } else {
+                uint32_t* meta = (uint32_t*)(base + kSliceElems * 4);
+                for (int i = 0; i < kSliceElems; ++i) meta[i] = (uint32_t)(w[i] >> 32);
+            }
+        }
+    }
+    return d;
 }
 
 }  // namespace hispmv

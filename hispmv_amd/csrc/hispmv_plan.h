@@ -16,7 +16,7 @@ namespace hispmv {
 
 constexpr int kFragBlock = 16;            // floats per x block (64 B: one cache-line sector)
 constexpr int kFragMaxLen = 2048;         // fragments longer than this are split so that wavefronts share the staging
-constexpr int kMaxLdsFloats = 38 * 1024;  // largest x window (152 KiB); the row-total tiles and carry slots come off it
+constexpr int kMaxLdsFloats = kCompactMaxIndex;   // largest x window: 32768 floats (128 KiB), what a compact meta can index
 
 struct GroupDesc {        // 16 B per workgroup
     int32_t frag_begin;   // first fragment of the group in the fragment table
@@ -52,5 +52,14 @@ LaunchPlan make_plan(SliceStream& st, int n_cus);
 
 // LDS floats one wavefront needs for the row totals of a slice (largest number of rows ending in one slice).
 int ytile_floats_for(const SliceStream& st);
+
+// Device form of a planned stream (hispmv_format.h: structure-of-arrays slices, compact or wide per GROUP -- a group is
+// compact when it has a window and none of its elements lies outside it).
+struct DeviceStream {
+    std::vector<uint8_t> bytes;          // the slices, group after group
+    std::vector<int32_t> groups;         // n_groups x {frag_begin, frag_count, offset of the group's first slice in kSliceUnit, 1 = compact}
+    int64_t compact_slices = 0;
+};
+DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan);
 
 }  // namespace hispmv

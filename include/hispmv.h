@@ -154,7 +154,8 @@ typedef struct hispmv_matrix_info {
     int32_t col_tile_width; /* columns per tile when col_tiles > 1, else 0 */
     int32_t col_tile_base;  /* tile t covers columns [base + t*width, base + (t+1)*width) of the range holding 99.8 % of the
                                elements; the first tile also takes every column below, the last every column above */
-    int32_t reserved;
+    int32_t compact_slices; /* slices stored with 6-byte elements (fp32 value + 16-bit {rowEnd, index into the LDS window of x}); the
+                               others take 8 bytes per element (32-bit meta) */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);
