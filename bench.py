@@ -3,18 +3,27 @@
 20-matrix SuiteSparse set of get_tb_matrices.py:57-78 (BASELINE.json configs[1]); metric = the
 reference's own GFLOP/s convention 2*(nnz+rows)/t (spmv-host.cpp:100,185) plus achieved HBM GB/s.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload set|powerlaw|dense|model] [--scaling weak|strong]
 
-A "step" is one pass over the set: one SpMV launch per matrix, back to back on one HIP stream,
-every operand already resident in HBM.  The working set of a step (~1.45 GB of packed stream) is
-far larger than the 256 MiB Infinity Cache, so every launch streams its matrix from HBM.
-SuiteSparse files cannot be downloaded here; matrices/<name>/<name>.mtx is used when present,
-otherwise the seeded stand-in with the real matrix's rows and nnz (hispmv_amd/matrices.py).
+--gpus N > 1 from a plain `python bench.py`: this process starts `python -m torch.distributed.run` with N ranks as a
+CHILD (before touching any GPU), relays rank 0's JSON line and exits with the children's status.  Started by
+torch.distributed.run itself (RANK/WORLD_SIZE in the environment) it is one of the ranks.
 
-N > 1 (weak scaling): rank k holds the k-th row block of the set scaled N-fold (same per-GPU nnz),
-split on the nnz prefix; x is replicated; the partial sums of rows cut by a rank boundary are
-exchanged with one RCCL all_gather per step (hispmv_amd/dist.py) -- never an all-reduce of y.
+A "step" is one pass over the workload, every operand already resident in HBM:
+  set       (default) one SpMV per matrix of the set, ONE hispmv_spmv_device_batch call.  ~1.2 GB of packed stream per
+            step, far more than the 256 MiB Infinity Cache: every launch streams from HBM.  SuiteSparse files cannot be
+            downloaded here; matrices/<name>/<name>.mtx is used when present, otherwise the seeded stand-in with the
+            real matrix's rows and nnz (hispmv_amd/matrices.py).  The JSON line also carries the pessimistic stand-in
+            family ("standin_uniform") and the strong-scaling figure of the six largest matrices ("strong_scaling").
+  powerlaw  BASELINE.json configs[2]: R-MAT scale 20 + Zipf(1.2) at soc-Pokec's shape
+  dense     the GeMV sizes of cpu/run_gemv.sh:9-13 (512 .. 8192 square) through the dense overlay
+  model     BASELINE.json configs[3]: the three layers of apps/model_test.py (dense 8192x4096, sparse 8192x8192 d=0.1,
+            sparse 1024x8192 d=0.25), device-resident vectors, one launch per layer
+
+N > 1: --scaling weak (default): rank k holds the k-th row block of the set scaled N-fold (same per-GPU nnz), split on
+the nnz prefix; --scaling strong: the six largest matrices (+ synthetic banded ones of --strong-gb GB)
+nnz-split over the ranks (hispmv_amd/dist.py: shard_csr).  x is replicated; the partial sums of rows cut by a rank
+boundary are exchanged with one RCCL all_gather per step -- never an all-reduce of y.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
 """
@@ -24,6 +33,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,6 +47,7 @@ sys.path.insert(0, str(ROOT))
 ALPHA, BETA = 0.55, -2.05            # common/src/spmv-host.cpp:43-44 (the FPGA/GPU drivers' scalars)
 HBM_PEAK_GBS = 8000.0                # MI355X spec (MI355X_MICROARCH.md, HBM)
 HW = ("bench.xclbin", 24, 1, 1, 2, 5, True, False, True)   # apps tuple; only sizes the default arena
+STRONG_SET = ["PFlow_742", "soc-Pokec", "mouse_gene", "TSOPF_RS_b2383", "Si41Ge41H72", "crankseg_2"]
 
 
 def parse_args():
@@ -43,12 +55,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["set", "powerlaw", "dense", "model"], default="set")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="what the main line measures when --gpus > 1")
+    ap.add_argument("--strong-gb", type=str, default="", help="comma-separated sizes (GB of stream) of synthetic row-shardable "
+                    "banded matrices added to the strong-scaling set, e.g. 2,4,8 (SURVEY.md 8d C5); generated rank-locally")
     ap.add_argument("--matrices", type=str, default="", help="comma-separated subset of the set (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the standin_uniform and strong_scaling sub-measurements")
+    ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds of timed CPU work per implementation and thread count")
     ap.add_argument("--per-matrix-reps", type=int, default=10)
     ap.add_argument("--details", type=str, default="", help="write the per-matrix table to this JSON file")
     ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the SpMVs of a step are spread over (independent matrices may overlap)")
+                    help="HIP streams the SpMVs of a step are spread over with --launch streams")
     ap.add_argument("--launch", choices=["batch", "streams"], default="batch",
                     help="batch: one hispmv_spmv_device_batch call per step (matrices with the same workgroup size share a "
                          "grid); streams: one launch per matrix, spread over --streams HIP streams")
@@ -57,98 +75,290 @@ def parse_args():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: N ranks as children of a process that never touches the GPU
+# ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for out in proc.stdout:                        # rank 0's JSON line is relayed; anything else goes to stderr
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: child processes without torch / HIP (oracle/cpu_baseline.py)
+# ------------------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    aff = sorted(os.sched_getaffinity(0))
+    cores = set()
+    for c in aff:
+        try:
+            base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+            cores.add((int((base / "physical_package_id").read_text()), int((base / "core_id").read_text())))
+        except Exception:
+            cores.add((0, c))
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    return dict(logical=len(aff), physical=len(cores), cgroup_cpu_max=quota)
+
+
+def cpu_baseline(workload: str, names, budget_s: float):
+    """kind "port": mkl_sparse_s_mv / cblas_sgemv called as cpu/src/main.cpp:26-49,74-96 does (when the box has
+    libmkl_rt) and the OpenMP restatement of cpu_spmv, each in a fresh child process that loads neither torch nor HIP,
+    pinned like cpu/env.sh:2-4, first-touched in parallel, on 24 threads (cpu/src/main.cpp:136) and on every physical
+    core the cgroup lets this process use; the best figure is reported with its thread count."""
+    info = host_cpu_info()
+    limit = info["physical"]
+    if info["cgroup_cpu_max"]:
+        limit = max(1, min(limit, int(info["cgroup_cpu_max"])))
+    counts = sorted({min(24, limit), limit})
+    script = str(ROOT / "oracle" / "cpu_baseline.py")
+    results, errors = {}, []
+    for impl in ("mkl", "omp"):
+        env = dict(os.environ)
+        env.update(OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_NUM_THREADS=str(max(counts)), MKL_NUM_THREADS=str(max(counts)),
+                   MKL_DYNAMIC="FALSE", OMP_DYNAMIC="FALSE")
+        env.pop("MKL_THREADING_LAYER", None)
+        cmd = [sys.executable, script, "--impl", impl, "--threads", ",".join(map(str, counts)), "--workload", workload,
+               "--budget", str(budget_s)] + (["--names", ",".join(names)] if names else []) + (["--one-thread"] if impl == "omp" else [])
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            line = [q for q in p.stdout.splitlines() if q.startswith("{")]
+            results[impl] = json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-300:]}
+        except Exception as ex:       # the baseline must never take the GPU number down with it
+            results[impl] = {"error": repr(ex)[:300]}
+        if "error" in results[impl]:
+            errors.append(f"{impl}: {results[impl]['error']}")
+    best = None
+    table = {}
+    for impl, r in results.items():
+        for run in r.get("runs", []):
+            if run.get("gflops"):
+                table[f"{impl}_{run['threads']}t_gflops"] = round(run["gflops"], 3)
+                if best is None or run["gflops"] > best[0]:
+                    best = (run["gflops"], run["threads"], impl)
+    one = results.get("omp", {}).get("one_thread_gflops")
+    out = {"value": round(best[0], 3) if best else None, "unit": "GFLOP/s", "cores": best[1] if best else 0, "kind": "port",
+           "impl": {"mkl": "cblas_sgemv (libmkl_rt via dlopen)" if workload == "dense" else "mkl_sparse_s_mv (+ cblas_sgemv for dense layers), libmkl_rt via dlopen",
+                    "omp": "OpenMP restatement of naive_gemv" if workload == "dense" else "OpenMP restatement of cpu_spmv (+ naive_gemv for dense layers)"}[best[2]] if best else None,
+           "threads_swept": counts, **table,
+           "cpu_spmv_1_thread_gflops": round(one, 3) if one else None,
+           "host": info,
+           "sample": f"the whole '{workload}' workload" + (f" ({','.join(names)})" if names else "") +
+                     f", per implementation and thread count about {budget_s:.0f} s of timed repetitions (<= 200 per matrix; reference: 200 each, "
+                     "cpu/run_spmv.sh:6), split over the matrices in proportion to their flops; child processes without torch/HIP, "
+                     "OMP_PLACES=cores OMP_PROC_BIND=close (cpu/env.sh:2-4), parallel first touch; vectors and alpha as cpu/src/main.cpp:147,173-178 "
+                     "(beta = 0 in the repeated calls: the reference's in-place loop overflows, SURVEY.md App. B.4)"}
+    if errors:
+        out["errors"] = errors
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
 def load_set(names, rank, world, uniform=False):
-    """-> list of dicts with the rank's CSR shard of every matrix (host arrays)."""
+    """-> list of dicts with the rank's CSR shard of every matrix (host arrays): weak-scaling layout."""
     from hispmv_amd import matrices as M
+    if world == 1:
+        return M.benchmark_set(names or None, uniform)
     out = []
     import zlib
     for name, rows, nnz, fam, par in M.SUITESPARSE_SET:
         if names and name not in names:
             continue
-        real = M.real_matrix_path(name)
-        if real is not None and world == 1:
-            out.append(dict(name=name, source="file:" + str(real), path=str(real)))
-            continue
         seed = zlib.crc32(name.encode())
         rp, ci, va, used = M.make_standin(name, rows, nnz, fam, par, seed + rank, uniform)
-        if world == 1:
-            out.append(dict(name=name, source=f"synthetic:{used}", rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
-            continue
         # N-fold scaled matrix = `world` stacked blocks; this rank's shard is cut inside rows on both sides
         from hispmv_amd.dist import shard_of_stacked_blocks
         nxt = M.make_standin(name, rows, nnz, fam, par, seed + rank + 1, uniform)[:3] if rank + 1 < world else None
         sh = shard_of_stacked_blocks((rp, ci, va), nxt, rows, rows, rank, world)
         out.append(dict(name=name, source=f"synthetic:{used}", rows=sh.n_rows, cols=rows * world, nnz=int(sh.row_ptr[-1]),
-                        rp=sh.row_ptr, ci=sh.col_idx, va=sh.values, shard=sh))
+                        rp=sh.row_ptr, ci=sh.col_idx, va=sh.values, shard=sh, x_touch=rows))
     return out
 
 
-def cpu_baseline(mats, budget_s=20.0):
-    """The oracle (kind "port") timed on the host cores over the same matrices: the OpenMP CSR
-    restatement of cpu/src/main.cpp:11-23 and, when the image has libmkl_rt, mkl_sparse_s_mv called
-    exactly as cpu/src/main.cpp:26-49 does (the reference's timed CPU path, 200 reps in
-    cpu/run_spmv.sh:6; here reps are bounded so the whole leg stays within ~budget_s)."""
-    import oracle   # checker/baseline only -- never on the product path
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    res = {"omp": [0.0, 0.0], "mkl": [0.0, 0.0]}
-    used = {"omp": cores, "mkl": 0}
-    per_matrix_budget = budget_s / max(1, len(mats)) / 2
-    sample = []
-    for m in mats:
+def load_strong(names, rank, world, gb_sizes):
+    """Strong scaling: every rank generates the whole stand-in and keeps its nnz-equal element range (shard_csr); the
+    synthetic GB-size banded matrices are 64 stacked row blocks of which a rank generates only its own."""
+    from hispmv_amd import matrices as M
+    from hispmv_amd.dist import shard_csr
+    out = []
+    for m in M.benchmark_set(names, False):
         if "rp" not in m:
             continue
-        rows, cols, nnz = m["rows"], m["cols"], m["nnz"]
-        x = ((np.arange(cols, dtype=np.float32) + 1) / (np.arange(cols, dtype=np.float32) + 2)).astype(np.float32)
-        y0 = (np.float32(-2.0) * (np.arange(rows, dtype=np.float32) + 1) / (np.arange(rows, dtype=np.float32) + 2)).astype(np.float32)
-        fl = 2.0 * (nnz + rows)
-        t1, nt, _ = oracle.omp_spmv_timed(m["rp"], m["ci"], m["va"], x, y0, 0.85, -2.06, 1)
-        reps = int(min(200, max(2, per_matrix_budget / max(t1, 1e-6))))
-        t, nt, _ = oracle.omp_spmv_timed(m["rp"], m["ci"], m["va"], x, y0, 0.85, -2.06, reps)
-        res["omp"][0] += fl * reps; res["omp"][1] += t * reps; used["omp"] = nt
-        if oracle.mkl_available():
-            r1 = oracle.mkl_spmv(m["rp"], m["ci"], m["va"], cols, x, y0, 0.85, -2.06, 1, cores)
-            if r1 is not None:
-                reps_m = int(min(200, max(2, per_matrix_budget / max(r1[0], 1e-6))))
-                r = oracle.mkl_spmv(m["rp"], m["ci"], m["va"], cols, x, y0, 0.85, 0.0, reps_m, cores)
-                res["mkl"][0] += fl * reps_m; res["mkl"][1] += r[0] * reps_m; used["mkl"] = r[1]
-        sample.append(m["name"])
-    # the reference's own single-thread loop (cpu_spmv, cpu/src/main.cpp:11-23) on the three largest matrices, one pass each
-    one_fl = one_t = 0.0
-    for m in sorted((q for q in mats if "rp" in q), key=lambda q: -q["nnz"])[:3]:
-        x = ((np.arange(m["cols"], dtype=np.float32) + 1) / (np.arange(m["cols"], dtype=np.float32) + 2)).astype(np.float32)
-        y0 = np.zeros(m["rows"], np.float32)
+        if world == 1:
+            out.append(dict(m, x_touch=m["cols"], full_rows=m["rows"], full_nnz=m["nnz"]))
+            continue
+        sh = shard_csr(m["rp"], m["ci"], m["va"], world, rank)
+        out.append(dict(name=m["name"], source=m["source"], rows=sh.n_rows, cols=m["cols"], nnz=int(sh.row_ptr[-1]), rp=sh.row_ptr,
+                        ci=sh.col_idx, va=sh.values, shard=sh, x_touch=m["cols"] // world, full_rows=m["rows"], full_nnz=m["nnz"]))
+    for gb in gb_sizes:
+        blocks, per_row, band = 64, 50, 20000
+        nnz_b = int(gb * 1e9 / 8 / blocks)
+        rows_b = nnz_b // per_row
+        mine = range(blocks * rank // world, blocks * (rank + 1) // world)
+        rps, cis, vas = [np.zeros(1, np.int64)], [], []
+        for b in mine:
+            rp, ci, va = M.synth_csr(rows_b, rows_b, nnz_b, "banded", band, 900 + b)
+            rps.append(rp[1:].astype(np.int64) + rps[-1][-1])
+            cis.append(ci.astype(np.int64) + b * rows_b)
+            vas.append(va)
+        rp = np.concatenate(rps)
+        assert rp[-1] < 2 ** 31
+        out.append(dict(name=f"banded_{gb:g}GB", source="synthetic:banded", rows=rows_b * len(mine), cols=rows_b * blocks, nnz=int(rp[-1]),
+                        rp=rp.astype(np.int32), ci=np.concatenate(cis).astype(np.int32), va=np.concatenate(vas), x_touch=rows_b * len(mine),
+                        full_rows=rows_b * blocks, full_nnz=nnz_b * blocks, shard=None))
+    return out
+
+
+def load_powerlaw():
+    from hispmv_amd import matrices as M
+    n, _, r, c, v = M.rmat_coo(20)
+    rp, ci, va = M.coo_to_csr_sorted(r, c, v, n)
+    out = [dict(name="rmat20", source="synthetic:rmat", rows=n, cols=n, nnz=int(rp[-1]), rp=rp, ci=ci, va=va)]
+    rp, ci, va = M.zipf_csr(1632803, 1632803, 30622600, 1.2, 7)
+    out.append(dict(name="zipf1.2_pokec_shape", source="synthetic:zipf", rows=1632803, cols=1632803, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
+    return out
+
+
+class Runner:
+    """One FpgaHandle, device vectors and a timing helper shared by the main measurement and the sub-measurements."""
+
+    def __init__(self, local_rank, world):
+        import torch
+        import pyhispmv
+        self.torch, self.world = torch, world
+        self.dev = torch.device("cuda", local_rank)
+        self.fpga = pyhispmv.FpgaHandle(HW[0], local_rank, *HW[1:])
+        self.fpga.set_arena_bytes(200 << 30)
+        # a dedicated (non-default) HIP stream: every launch, event and collective of a timed region is on it
+        self.stream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.stream)
+        self.sptr = self.stream.cuda_stream
+        assert self.sptr != 0
+
+    def add(self, mats):
+        """Creates the handles (sparse from CSR / file, dense from an array), loads them, attaches device vectors."""
+        torch, fpga = self.torch, self.fpga
+        t0 = time.time()
+        for m in mats:
+            if m.get("dense") is not None:
+                m["idx"] = fpga.create_dense_handle(m["dense"].reshape(-1), m["rows"], m["cols"])
+            elif "path" in m:
+                m["idx"] = fpga.create_sparse_handle_from_mtx(m["path"], 0)
+            else:
+                m["idx"] = fpga.create_sparse_handle_from_csr(m["rp"], m["ci"], m["va"], m["rows"], m["cols"])
+            assert m["idx"] >= 0, f"{m['name']}: arena full"
+        fpga.load_matrices()
+        t_prep = time.time() - t0
+        for m in mats:
+            info = fpga.matrix_info(m["idx"])
+            m.update(rows=info["rows"], cols=info["cols"], nnz=info["nnz"], n_slices=info["n_slices"], device_bytes=info["device_bytes"],
+                     prep_seconds=info["prep_seconds"], n_split=info["n_split_rows"], compact_slices=info["compact_slices"],
+                     plan=f'{info["block_threads"]}t/{info["group_slices"]}s/{info["lds_bytes"] // 1024}KiB/{info["col_tiles"]}ct'
+                          + (f'/{100 * info["compact_slices"] // max(1, info["n_slices"])}%c' if not info["is_dense"] else ""))
+            g = torch.Generator(device="cpu").manual_seed(1234 + m["idx"])
+            m["x"] = torch.rand(m["cols"], generator=g, dtype=torch.float32).to(self.dev)
+            m["b"] = torch.rand(m["rows"], generator=g, dtype=torch.float32).to(self.dev)
+            m["y"] = torch.zeros(m["rows"], dtype=torch.float32, device=self.dev)
+            if m.get("shard") is not None and m["shard"].tail_open:
+                m["b"][-1] = 0.0        # the cut row belongs to the next rank: this rank only contributes alpha*partial
+        return t_prep
+
+    def batch_step(self, mats, exch=None):
+        fpga, sptr = self.fpga, self.sptr
+        batch = fpga.prepare_batch([m["idx"] for m in mats], [m["x"].data_ptr() for m in mats], [m["b"].data_ptr() for m in mats],
+                                   [m["y"].data_ptr() for m in mats])
+        if exch is not None:
+            exch.prepare(mats)
+
+            def step():
+                fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
+                exch.run(mats, ALPHA, prepared=True)
+        else:
+            def step():
+                fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
+        return step
+
+    def fence(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def time_steps(self, step, steps, warmup):
+        """EXACTLY `steps` steps between two fences (barrier + device synchronise), HIP events on the launch stream;
+        -> (wall seconds, device seconds), max over ranks."""
+        torch = self.torch
+        for _ in range(warmup):
+            step()
+        self.fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        oracle.cpu_spmv(m["rp"], m["ci"], m["va"], x, y0, 0.85, -2.06, 1)
-        one_t += time.perf_counter() - t0
-        one_fl += 2.0 * (m["nnz"] + m["rows"])
-    omp = res["omp"][0] / res["omp"][1] / 1e9 if res["omp"][1] > 0 else None
-    mkl = res["mkl"][0] / res["mkl"][1] / 1e9 if res["mkl"][1] > 0 else None
-    primary = "mkl_sparse_s_mv" if mkl is not None else "openmp_csr"
-    return {
-        "value": round(mkl if mkl is not None else omp, 3), "unit": "GFLOP/s",
-        "cores": used["mkl"] if mkl is not None else used["omp"], "kind": "port", "impl": primary,
-        "openmp_csr_gflops": None if omp is None else round(omp, 3),
-        "mkl_gflops": None if mkl is None else round(mkl, 3),
-        "cpu_spmv_1_thread_gflops": round(one_fl / one_t / 1e9, 3) if one_t > 0 else None,
-        "sample": f"{len(sample)} matrices of the same set ({', '.join(sample[:3])}...), reps bounded to ~{budget_s:.0f} s total "
-                  f"(reference: 200 reps each, cpu/run_spmv.sh:6), alpha=0.85 beta=-2.06 as cpu/src/main.cpp:147-148",
-    }
+        ev0.record(self.stream)
+        for _ in range(steps):
+            step()
+        ev1.record(self.stream)
+        self.fence()
+        t_wall = time.perf_counter() - t0
+        t_dev = ev0.elapsed_time(ev1) * 1e-3
+        self.fpga.synchronize()                       # raises if a bounded in-kernel wait (carry look-back) expired
+        if self.world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([t_wall, t_dev], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_wall, t_dev = float(tt[0]), float(tt[1])
+        return t_wall, t_dev
 
 
+def latest_traffic(n_launches):
+    """HBM bytes per launch from the newest committed PMC summary (tools/profile_round.sh: FETCH_SIZE x2 + WRITE_SIZE in
+    separate passes, MI355X_MICROARCH.md "HBM")."""
+    cands = sorted((ROOT / "profiles").glob("*_traffic.json"), key=lambda q: q.stat().st_mtime)
+    for c in reversed(cands):
+        try:
+            tj = json.loads(c.read_text())
+            return int(tj["hbm_bytes_per_step"] / max(1, n_launches)), f"profiles/{c.name}"
+        except Exception:
+            continue
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_torchrun:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
-    import pyhispmv
     from hispmv_amd import matrices as M
 
     # HISPMV_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- rehearses the N > 1 code path on a
@@ -157,129 +367,105 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = dist.get_backend()
+    ranks_seen = dist.get_world_size() if world > 1 else 1
 
     names = [n for n in args.matrices.split(",") if n]
+    gb_sizes = [float(q) for q in args.strong_gb.split(",") if q]
+    R = Runner(local_rank, world)
+    fpga, sptr, stream = R.fpga, R.sptr, R.stream
+    strong_main = world > 1 and args.scaling == "strong" and args.workload == "set"
+
     t0 = time.time()
-    mats = load_set(names, rank, world, args.standin == "uniform")
+    if args.workload == "set":
+        mats = load_strong(names or STRONG_SET, rank, world, gb_sizes) if strong_main else load_set(names, rank, world, args.standin == "uniform")
+    elif args.workload == "powerlaw":
+        mats = load_powerlaw()
+    elif args.workload == "dense":
+        rng = np.random.default_rng(0)
+        mats = [dict(name=f"gemv_{n}x{n}", source="synthetic:dense", rows=n, cols=n, dense=rng.random((n, n), dtype=np.float32) - np.float32(0.5))
+                for n in (512, 1024, 2048, 4096, 8192)]                                   # cpu/run_gemv.sh:9-13
+    else:
+        mats = []
+        for i, (kind, W, rows, cols, _bias) in enumerate(M.model_test_layers(0)):
+            if kind == "dense":
+                mats.append(dict(name=f"layer{i}_dense_{rows}x{cols}", source="synthetic:model_test", rows=rows, cols=cols, dense=W))
+            else:
+                rp, ci, va = M.coo_to_csr_sorted(W[0], W[1], W[2], rows)
+                mats.append(dict(name=f"layer{i}_sparse_{rows}x{cols}", source="synthetic:model_test", rows=rows, cols=cols, rp=rp, ci=ci, va=va))
+    assert world == 1 or args.workload == "set", "--gpus > 1 is defined for the SuiteSparse set"
     t_gen = time.time() - t0
+    t_prep = R.add(mats)
 
-    fpga = pyhispmv.FpgaHandle(HW[0], local_rank, *HW[1:])
-    fpga.set_arena_bytes(64 << 30)
-    t0 = time.time()
-    for m in mats:
-        if "path" in m:
-            m["idx"] = fpga.create_sparse_handle_from_mtx(m["path"], 0)
-        else:
-            m["idx"] = fpga.create_sparse_handle_from_csr(m["rp"], m["ci"], m["va"], m["rows"], m["cols"])
-        assert m["idx"] >= 0, f"{m['name']}: arena full"
-    fpga.load_matrices()
-    t_prep = time.time() - t0
-    for m in mats:
-        info = fpga.matrix_info(m["idx"])
-        m.update(rows=info["rows"], cols=info["cols"], nnz=info["nnz"], n_slices=info["n_slices"],
-                 device_bytes=info["device_bytes"], prep_seconds=info["prep_seconds"], n_split=info["n_split_rows"],
-                 plan=f'{info["block_threads"]}t/{info["group_slices"]}s/{info["lds_bytes"] // 1024}KiB/{info["col_tiles"]}ct')
-        g = torch.Generator(device="cpu").manual_seed(1234 + m["idx"])
-        m["x"] = torch.rand(m["cols"], generator=g, dtype=torch.float32).to(dev)
-        m["b"] = torch.rand(m["rows"], generator=g, dtype=torch.float32).to(dev)
-        m["y"] = torch.zeros(m["rows"], dtype=torch.float32, device=dev)
-        if m.get("shard") is not None and m["shard"].tail_open:
-            m["b"][-1] = 0.0        # the cut row belongs to the next rank: this rank only contributes alpha*partial
-
-    # a dedicated (non-default) HIP stream: every launch, event and collective of the timed region is on it
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    sptr = stream.cuda_stream
-    assert sptr != 0
+    exch = None
     if world > 1:
         from hispmv_amd.dist import BoundaryExchange
-        exch = BoundaryExchange(len(mats), dev)
+        exch = BoundaryExchange(len(mats), R.dev)
 
-    # optional extra streams: the matrices of a step are independent, so their launches may overlap; every
-    # side stream is fenced against the main stream's start and end events
-    n_streams = max(1, args.streams)
-    side = [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
-    lanes = [stream] + side
-    # longest-processing-time-first: one untimed pass measures each launch alone, then every matrix goes to the
-    # stream with the least work so far
-    cost = {}
-    for i, m in enumerate(mats):
-        fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
-        a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a_ev.record(stream)
-        fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
-        b_ev.record(stream)
-        torch.cuda.synchronize()
-        cost[i] = a_ev.elapsed_time(b_ev)
-    order = sorted(range(len(mats)), key=lambda i: -cost[i])
-    load = [0.0] * n_streams
-    for i in order:
-        k = min(range(n_streams), key=lambda q: load[q])
-        mats[i]["lane"] = k
-        load[k] += cost[i]
-
-    batch = fpga.prepare_batch([m["idx"] for m in mats], [m["x"].data_ptr() for m in mats], [m["b"].data_ptr() for m in mats],
-                               [m["y"].data_ptr() for m in mats])
-
-    def step_batch():
-        fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
-        if world > 1:
-            exch.run(mats, ALPHA)
-
-    def step_streams():
-        if n_streams > 1:
-            fork = torch.cuda.Event()
-            fork.record(stream)
-            for s2 in side:
-                s2.wait_event(fork)
-        for i in order:
-            m = mats[i]
-            fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA,
-                             lanes[m["lane"]].cuda_stream)
-        if n_streams > 1:
-            for s2 in side:
-                join = torch.cuda.Event()
-                join.record(s2)
-                stream.wait_event(join)
-        if world > 1:
-            exch.run(mats, ALPHA)
-
-    step = step_batch if args.launch == "batch" else step_streams
+    # ---- the main timed region --------------------------------------------------------------------------------------
+    n_streams = 1
     if args.launch == "batch":
-        n_streams = 1
+        step = R.batch_step(mats, exch)
+    else:
+        # one launch per matrix over --streams HIP streams: longest-processing-time-first assignment from one untimed pass
+        n_streams = max(1, args.streams)
+        side = [torch.cuda.Stream(device=R.dev) for _ in range(n_streams - 1)]
+        lanes = [stream] + side
+        cost = {}
+        for i, m in enumerate(mats):
+            fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
+            a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_ev.record(stream)
+            fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, sptr)
+            b_ev.record(stream)
+            torch.cuda.synchronize()
+            cost[i] = a_ev.elapsed_time(b_ev)
+        order = sorted(range(len(mats)), key=lambda i: -cost[i])
+        load = [0.0] * n_streams
+        for i in order:
+            k = min(range(n_streams), key=lambda q: load[q])
+            mats[i]["lane"] = k
+            load[k] += cost[i]
+        if exch is not None:
+            exch.prepare(mats)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():
+            if n_streams > 1:
+                fork = torch.cuda.Event()
+                fork.record(stream)
+                for s2 in side:
+                    s2.wait_event(fork)
+            for i in order:
+                m = mats[i]
+                fpga.spmv_device(m["idx"], m["x"].data_ptr(), m["b"].data_ptr(), m["y"].data_ptr(), ALPHA, BETA, lanes[m["lane"]].cuda_stream)
+            if n_streams > 1:
+                for s2 in side:
+                    join = torch.cuda.Event()
+                    join.record(s2)
+                    stream.wait_event(join)
+            if exch is not None:
+                exch.run(mats, ALPHA, prepared=True)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    fence()
-    t_wall = time.perf_counter() - t_start
-    t_dev = ev0.elapsed_time(ev1) * 1e-3          # HIP events on the launch stream
-    fpga.synchronize()                            # raises if a bounded in-kernel wait (carry look-back) expired
-    if world > 1:
-        tt = torch.tensor([t_wall, t_dev], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_wall, t_dev = float(tt[0]), float(tt[1])
+    t_wall, t_dev = R.time_steps(step, args.steps, args.warmup)
 
-    # per-matrix table (outside the timed region): events around `reps` launches of one matrix; the
-    # other matrices are touched in between so that each measurement starts from a cold Infinity Cache
+    def alg_bytes(m):
+        if m.get("dense") is not None:
+            return 4 * m["rows"] * m["cols"] + 4 * m["cols"] + 8 * m["rows"]               # B_gemv
+        # (x is replicated at full length on every rank, but a rank's block touches about 1/world of it: count that part)
+        return M.algorithmic_bytes(m["rows"], m.get("x_touch", m["cols"]), m["nnz"])
+
+    def flops_of(m):
+        return 2 * m["rows"] * m["cols"] + m["rows"] if m.get("dense") is not None else M.flops(m["rows"], m["nnz"])     # cpu/src/main.cpp:233 / :187
+
+    # ---- per-matrix table (outside the timed region): events around one launch of one matrix; the largest matrix
+    # is streamed in between so that each measurement starts from a cold Infinity Cache
     table = []
     if rank == 0 and args.per_matrix_reps > 0:
         big = max(mats, key=lambda q: q["device_bytes"])
@@ -295,58 +481,100 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b) * 1e-3)
             t = float(np.median(ts))
-            ab = M.algorithmic_bytes(m["rows"], m["cols"] // world, m["nnz"])
+            ab = alg_bytes(m)
             table.append(dict(name=m["name"], source=m["source"], rows=m["rows"], nnz=m["nnz"], us=round(t * 1e6, 2),
-                              gflops=round(M.flops(m["rows"], m["nnz"]) / t / 1e9, 2), alg_gbs=round(ab / t / 1e9, 1),
+                              gflops=round(flops_of(m) / t / 1e9, 2), alg_gbs=round(ab / t / 1e9, 1),
                               pct_hbm_peak=round(100 * ab / t / 1e9 / HBM_PEAK_GBS, 2), slices=m["n_slices"],
                               split_rows=m["n_split"], prep_s=round(m["prep_seconds"], 3), plan=m["plan"]))
 
-    flops_step = sum(M.flops(m["rows"], m["nnz"]) for m in mats)
-    # (x is replicated at full length on every rank, but a rank's block touches 1/world of it: count that part)
-    bytes_step = sum(M.algorithmic_bytes(m["rows"], m["cols"] // world, m["nnz"]) for m in mats)
+    flops_step = sum(flops_of(m) for m in mats)
+    bytes_step = sum(alg_bytes(m) for m in mats)
+
+    # ---- sub-measurements (same JSON line, so that neither stand-in family nor scaling mode is cherry-picked) ----------
+    extras = {}
+    if args.workload == "set" and not args.no_extras and not names and args.launch == "batch":
+        if world == 1 and args.standin == "structured":
+            # the pessimistic family: the 8 mesh-origin matrices as unstructured bands (no column reuse between rows)
+            uni = [m for m in M.benchmark_set(None, True) if m.get("family") == "fem"]
+            R.add(uni)
+            swapped = [next((u for u in uni if u["name"] == m["name"]), m) for m in mats]
+            tw, td = R.time_steps(R.batch_step(swapped), args.steps, args.warmup)
+            fl, by = sum(flops_of(m) for m in swapped), sum(alg_bytes(m) for m in swapped)
+            extras["standin_uniform"] = {"value": round(fl * args.steps / tw / 1e9, 2), "unit": "GFLOP/s", "ms_per_step": round(tw / args.steps * 1e3, 4),
+                                         "roofline_frac": round(by * args.steps / td / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "same step with the 8 mesh-origin matrices generated as unstructured bands (--standin uniform)"}
+        if not strong_main:
+            # strong scaling of the six largest matrices: the SAME matrices at every N, nnz-split over the ranks
+            smats = [m for m in mats if m["name"] in STRONG_SET] if world == 1 else load_strong(STRONG_SET, rank, world, gb_sizes)
+            if world == 1 and gb_sizes:
+                extra_gb = [m for m in load_strong([], rank, world, gb_sizes)]
+                R.add(extra_gb)
+                smats = smats + extra_gb
+            if world > 1:
+                R.add(smats)
+            sexch = None
+            if world > 1:
+                from hispmv_amd.dist import BoundaryExchange
+                sexch = BoundaryExchange(len(smats), R.dev)
+            tw, td = R.time_steps(R.batch_step(smats, sexch), args.steps, args.warmup)
+            fl = sum(M.flops(m.get("full_rows", m["rows"]), m.get("full_nnz", m["nnz"])) for m in smats)
+            by = sum(M.algorithmic_bytes(m.get("full_rows", m["rows"]), m["cols"], m.get("full_nnz", m["nnz"])) for m in smats)
+            extras["strong_scaling"] = {"matrices": [m["name"] for m in smats], "n_gpus": world, "value": round(fl * args.steps / tw / 1e9, 2),
+                                        "unit": "GFLOP/s", "ms_per_step": round(tw / args.steps * 1e3, 4),
+                                        "hbm_gbs_algorithmic": round(by * args.steps / tw / 1e9, 1), "scaling": "strong",
+                                        "note": "whole-job rate of the same matrices nnz-split over n_gpus ranks (shard_csr); speed-up = value / the n_gpus = 1 value"}
+
     if rank == 0:
-        total_flops = flops_step * world * args.steps
-        total_bytes = bytes_step * world * args.steps
+        if strong_main:
+            total_flops = sum(M.flops(m["full_rows"], m["full_nnz"]) for m in mats) * args.steps
+            total_bytes = sum(M.algorithmic_bytes(m["full_rows"], m["cols"], m["full_nnz"]) for m in mats) * args.steps
+        else:
+            total_flops = flops_step * world * args.steps
+            total_bytes = bytes_step * world * args.steps
         value = total_flops / t_wall / 1e9
         achieved = bytes_step * args.steps / t_dev / 1e9          # per GPU, device time
         launches = len(mats) * args.steps
         geo = math.exp(sum(math.log(r["gflops"]) for r in table) / len(table)) if table else None
-        # HBM traffic per launch from the PMC passes of tools/profile_round.sh (same command under rocprofv3;
-        # FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), if a summary has been committed
-        traffic, traffic_src = None, None
-        cands = sorted((ROOT / "profiles").glob("*_traffic.json"), key=lambda q: q.stat().st_mtime)
-        if cands and world == 1 and not names:
-            try:
-                tj = json.loads(cands[-1].read_text())
-                traffic = int(tj["hbm_bytes_per_step"] / max(1, len(mats)))
-                traffic_src = f"profiles/{cands[-1].name}"
-            except Exception:
-                traffic = None
+        traffic, traffic_src = latest_traffic(len(mats)) if (world == 1 and not names and args.workload == "set") else (None, None)
+        workloads = {"set": "BASELINE.json configs[1]: full get_tb_matrices.py SuiteSparse set, one SpMV per matrix per step",
+                     "powerlaw": "BASELINE.json configs[2]: R-MAT scale 20 (ef 16, duplicates kept) + Zipf(1.2) row lengths at soc-Pokec's shape",
+                     "dense": "dense overlay GeMV, sizes of cpu/run_gemv.sh:9-13 (512..8192 square)",
+                     "model": "BASELINE.json configs[3]: apps/model_test.py layers 4096->8192 dense, 8192->8192 d=0.1, 8192->1024 d=0.25, one launch per layer"}
+        dominant = {"set": "spmv_slices_multi_kernel (matrices of one workgroup size share a grid; + one fix-up and one merge launch per step)"
+                           if args.launch == "batch" else "spmv_slices_kernel (+ carry fix-up launches)",
+                    "powerlaw": "spmv_slices_multi_kernel", "dense": "gemv_rows_kernel", "model": "gemv_rows_kernel + spmv_slices_multi_kernel"}[args.workload]
         out = {
-            "metric": "SpMV GFLOP/s, SuiteSparse set (20 matrices), fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
+            "metric": {"set": "SpMV GFLOP/s, SuiteSparse set (20 matrices), fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
+                       "powerlaw": "SpMV GFLOP/s, power-law matrices, fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
+                       "dense": "GeMV GFLOP/s, dense overlay, fp32 y=alpha*W*x+beta*y, flops=2*rows*cols+rows",
+                       "model": "GFLOP/s over the three model_test layers (dense + sparse), fp32"}[args.workload],
             "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(t_wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(t_wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong_main else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: full get_tb_matrices.py SuiteSparse set, one SpMV per matrix per step"
-                                   + (f", scaled {world}x in rows and nnz-split over {world} GPUs" if world > 1 else ""),
+            "config": {"workload": workloads[args.workload]
+                                   + (f", the six largest matrices nnz-split over {world} GPUs" if strong_main else
+                                      f", scaled {world}x in rows and nnz-split over {world} GPUs" if world > 1 else ""),
                        "matrices": len(mats), "nnz_per_step_per_gpu": int(sum(m["nnz"] for m in mats)),
-                       "sources": sorted(set(m["source"].split(":")[0] for m in mats)),
-                       "alpha": ALPHA, "beta": BETA, "launch": args.launch, "streams": n_streams, "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
-            "passes_over_set": args.warmup + args.steps + 2,   # + the two untimed passes that size the stream assignment
+                       "sources": sorted(set(m["source"].split(":")[0] for m in mats)), "standin": args.standin,
+                       "alpha": ALPHA, "beta": BETA, "launch": args.launch, "streams": n_streams,
+                       "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
+            "ranks_seen": ranks_seen, "backend": backend,
+            "passes_over_set": args.warmup + args.steps + (2 if args.launch == "streams" else 0),
             "hbm_gbs_algorithmic": round(total_bytes / t_wall / 1e9, 1),
             "hbm_pct_of_peak": round(100 * total_bytes / t_wall / 1e9 / (HBM_PEAK_GBS * world), 2),
             "geomean_gflops_per_matrix": None if geo is None else round(geo, 2),
-            "roofline": {"bound": "hbm", "kernel": ("spmv_slices_multi_kernel (matrices of one workgroup size share a grid; + one fix-up launch per round)"
-                                                    if args.launch == "batch" else "spmv_slices_kernel (+ carry fix-up launches)"),
+            "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch_avg": int(bytes_step / len(mats)),
                          "avg_launch_us": round(t_dev / launches * 1e6, 3),
-                         "note": "achieved = sum over the set of (8*nnz+16*rows+4) B / HIP-event time of the timed region on the launch stream"},
+                         "note": "achieved = sum over the workload of the algorithmic bytes (SpMV: 8*nnz+16*rows+4, GeMV: 4*rows*cols+4*cols+8*rows) "
+                                 "/ HIP-event time of the timed region on the launch stream"},
             "host": {"gen_s": round(t_gen, 1), "prep_upload_s": round(t_prep, 1)},
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mats)
+            out["cpu_baseline"] = cpu_baseline(args.workload, names, args.cpu_budget)
         else:
             out["cpu_baseline"] = None
         if args.details:

@@ -191,18 +191,31 @@ class BoundaryExchange:
         self._d_first = torch.tensor(first, dtype=torch.int64, device=self.device)
         self._w = self.weights.to(torch.float32).contiguous()
 
-    def run(self, mats, alpha: float = 1.0) -> None:
+    def prepare(self, mats) -> None:
+        """Everything `run` needs that does not change from step to step (flags, chain weights, the device tables of
+        pointers, the stream handle): call once, then `run(..., prepared=True)` does no Python work per matrix."""
+        if not self.ready:
+            self._setup(mats)
+        if self.send.is_cuda:
+            self._device_tables(mats)
+            self._stream = self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def run(self, mats, alpha: float = 1.0, prepared: bool = False) -> None:
         """After every rank's local SpMV of every matrix: publish the tails (y_local[-1] of rows this rank
         does not own: alpha*partial, its bias entry was zeroed), gather them, add the chain into the owner's
         first row.  On the GPU: two tiny launches of libhispmv around ONE all_gather (a chain of ~30 torch
-        element ops would cost about half a step of the 20-matrix set)."""
+        element ops would cost about half a step of the 20-matrix set).  prepared=True: `prepare` was called and
+        neither the y tensors nor the current stream changed since."""
         torch = self.torch
         if not self.ready:
             self._setup(mats)
         if self.send.is_cuda:
             from ._lib import lib
-            self._device_tables(mats)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if prepared:
+                stream = self._stream
+            else:
+                self._device_tables(mats)
+                stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = lib.hispmv_boundary_pack(self._d_last.data_ptr(), self.tail_mask.data_ptr(), self.send.data_ptr(), self.n, stream)
             if rc != 0:
                 raise RuntimeError(f"hispmv_boundary_pack failed ({rc})")

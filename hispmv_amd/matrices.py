@@ -299,6 +299,14 @@ def model_test_layers(seed: int = 0):
     return out
 
 
+def coo_to_csr_sorted(r, c, v, rows: int):
+    """COO (duplicates kept) -> CSR with rows ascending and columns ascending inside a row (stable)."""
+    order = np.lexsort((c, r))
+    rp = np.zeros(rows + 1, np.int64)
+    np.add.at(rp, np.asarray(r, np.int64) + 1, 1)
+    return np.cumsum(rp).astype(np.int32), np.asarray(c, np.int32)[order], np.asarray(v, np.float32)[order]
+
+
 def benchmark_set(names=None, uniform: bool = False, seed_shift: int = 0):
     """The matrices of a bench step (BASELINE.json configs[1]), exactly as bench.py and the parity tests build them:
     a real file under matrices/<name>/ when present, else the seeded stand-in.  -> list of dicts with

@@ -49,6 +49,10 @@ def _load():
     lib.orc_mkl_available.restype = C.c_int
     lib.orc_mkl_spmv.argtypes = [C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_int, C.c_int, _ip]
     lib.orc_mkl_spmv.restype = C.c_double
+    lib.orc_cpu_bench_spmv.argtypes = [C.c_int, C.c_int, _p, _p, _p, C.c_int, C.c_int, C.c_double, C.c_int, _ip]
+    lib.orc_cpu_bench_spmv.restype = C.c_double
+    lib.orc_cpu_bench_gemv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _ip]
+    lib.orc_cpu_bench_gemv.restype = C.c_double
     lib.refpack_create.argtypes = [C.c_int] * 8
     lib.refpack_create.restype = _p
     lib.refpack_free.argtypes = [_p]
@@ -195,6 +199,20 @@ def mkl_spmv(row_ptr, col_idx, vals, cols, x, y0, alpha, beta, reps=1, threads=0
     if t < 0:
         return None
     return t, nt.value, y
+
+
+def cpu_bench_spmv(row_ptr, col_idx, vals, cols, mode, threads, budget_s, max_reps=200):
+    """Baseline timing with first-touched copies (hispmv_oracle.cpp section 5) -> (seconds per rep, reps) or None."""
+    rp, ci, va = _c(row_ptr, np.int32), _c(col_idx, np.int32), _c(vals, np.float32)
+    reps = C.c_int()
+    t = lib.orc_cpu_bench_spmv(rp.size - 1, int(cols), _ptr(rp), _ptr(ci), _ptr(va), int(mode), int(threads), float(budget_s), int(max_reps), C.byref(reps))
+    return None if t < 0 else (t, reps.value)
+
+
+def cpu_bench_gemv(rows, cols, mode, threads, budget_s, max_reps=10000):
+    reps = C.c_int()
+    t = lib.orc_cpu_bench_gemv(int(rows), int(cols), int(mode), int(threads), float(budget_s), int(max_reps), C.byref(reps))
+    return None if t < 0 else (t, reps.value)
 
 
 class RefPack:

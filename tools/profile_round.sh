@@ -10,7 +10,7 @@ TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --per-matrix-reps 0 $*"   # bench.py defaults (--launch batch); passes over the set are read from its JSON line
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-extras --per-matrix-reps 0 $*"   # bench.py defaults (--launch batch); passes over the set are read from its JSON line
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || echo "trace pass failed"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $ARGS > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py $ARGS > "$OUT/write.log" 2>&1 || echo "write pass failed"
