@@ -21,6 +21,7 @@ import scipy.sparse as sp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pyhispmv  # noqa: E402
+from hispmv_amd.report import print_error_stats  # noqa: E402
 
 ALPHA, BETA = 0.55, -2.05
 
@@ -28,26 +29,6 @@ ALPHA, BETA = 0.55, -2.05
 def generate_vector(n):
     i = np.arange(n, dtype=np.float32)
     return (np.float32(1.0) * (i + 2) / (i + 1)).astype(np.float32)
-
-
-def print_error_stats(cpu_ref, out):
-    fp, cp = np.abs(out.astype(np.float64)), np.abs(cpu_ref.astype(np.float64))
-    with np.errstate(divide="ignore", invalid="ignore"):
-        rel = np.abs(fp - cp) / cp
-    rel = rel[np.isfinite(rel) & (rel != 0)]
-    if rel.size == 0:
-        print("No mismatch found")
-        return
-    if rel.size <= 10:
-        print("Found atmost 10 mismatches, Relative Errors:")
-        for e in rel:
-            print(f"\t{e}")
-        return
-    lo, hi = rel.min(), rel.max()
-    counts, edges = np.histogram(rel, bins=10, range=(lo, hi if hi > lo else lo + 1e-30))
-    print("Relative Error Range:\tCount")
-    for k in range(10):
-        print(f"[{edges[k]:.3e}, {edges[k + 1]:.3e}):\t{counts[k]}")
 
 
 def main():
@@ -95,6 +76,19 @@ def main():
     print("Using Num samples: 1")
     print("\nComputing on GPU...")
     ms = fpga.time_device(idx, dx.data_ptr(), dc.data_ptr(), dy.data_ptr(), ALPHA, BETA, reps)
+    power = []
+    try:                                      # FpgaPowerMonitor's role (spmv-host.cpp:113-141), when the driver exposes it
+        for _ in range(5):
+            fpga.time_device(idx, dx.data_ptr(), dc.data_ptr(), dy.data_ptr(), ALPHA, BETA, max(1, reps // 5))
+            p_now = float(torch.cuda.power_draw(a.device))          # mW by the documentation; W from the ROCm backend here
+            power.append(p_now / 1000.0 if p_now > 5000.0 else p_now)
+    except Exception:
+        power = []
+    if power:
+        for w in power:
+            print(f"sample: {w:.3f}")
+        print(f"Average Power: {sum(power) / len(power):.3f} Watts")
+        print(f"Max Power: {max(power):.3f} Watts")
     print(f"Total Kernel Runtime: {ms * reps:.6f}ms ")
     print(f"FPGA TIME: {ms * 1e3:.4f}us ")
     print(f"FPGA GFLOPS: {2.0 * (nnz + rows) / (ms * 1e-3) / 1e9:.4f}")

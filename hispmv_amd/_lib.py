@@ -68,6 +68,7 @@ SIGNATURES = {
     "hispmv_get_matrix_info": (C.c_int, [_p, C.c_int, C.POINTER(MatrixInfo)]),
     "hispmv_num_matrices": (C.c_int, [_p]),
     "hispmv_prep_from_coo": (C.c_int, [C.POINTER(_p), _p, _p, _p, C.c_int64, C.c_int32, C.c_int32]),
+    "hispmv_prep_from_coo_device": (C.c_int, [C.POINTER(_p), C.c_int, _p, _p, _p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "hispmv_prep_from_mtx": (C.c_int, [C.POINTER(_p), C.c_char_p, C.c_int]),
     "hispmv_prep_free": (None, [_p]),
     "hispmv_prep_last_error": (C.c_char_p, []),

@@ -21,6 +21,7 @@
 #include "hispmv_kernels.h"
 #include "hispmv_plan.h"
 #include "hispmv_prep.h"
+#include "hispmv_prep_device.h"
 
 #define HISPMV_API extern "C" __attribute__((visibility("default")))
 
@@ -102,6 +103,10 @@ struct hispmv_ctx {
     // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
     // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.
     int carry_mode = 2;          // 0 fixup, 1 lookback, 2 auto (HISPMV_CARRY)
+    // COO -> CSR -> slice stream: 0 on the host (OpenMP), 1 on the device (hispmv_prep_device.hip), 2 auto = device from
+    // 2 M entries (HISPMV_PREP=host|device|auto); both give the same stream byte for byte
+    int prep_mode = 2;
+    DevicePrepTimes last_prep_times;
     int n_cus = 256;
 };
 
@@ -228,12 +233,12 @@ void finish_part(Matrix::Part& p, int n_cus) {
 
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
 // "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).
-int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr) {
+int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
     auto m = std::make_unique<Matrix>();
     m->rows = csr.rows; m->cols = csr.cols; m->nnz = csr.nnz();
     m->parts.emplace_back();
-    m->parts[0].st = build_stream(csr);
+    m->parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
     finish_part(m->parts[0], c->n_cus);
     // Column tiling when the whole-matrix plan has to gather x through L2:
     //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
@@ -449,6 +454,8 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
+    if (const char* env = std::getenv("HISPMV_PREP"))
+        c->prep_mode = !std::strcmp(env, "host") ? 0 : !std::strcmp(env, "device") ? 1 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* env = std::getenv("HISPMV_PLAN_CUS")) { const int v = std::atoi(env); if (v > 0) c->n_cus = v; }   // experiments
     *out = c.release();
@@ -479,16 +486,30 @@ HISPMV_API int hispmv_set_arena_bytes(hispmv_ctx* c, int64_t bytes) {
 }
 HISPMV_API int64_t hispmv_arena_bytes_used(const hispmv_ctx* c) { return c ? c->arena_used : 0; }
 
+// COO -> handle, on the device or on the host (hispmv_ctx::prep_mode)
+static int add_from_coo(hispmv_ctx* c, int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const int32_t* cl, const float* v) {
+    auto t0 = std::chrono::steady_clock::now();
+    const bool on_device = c->prep_mode == 1 || (c->prep_mode == 2 && nnz >= (2 << 20));
+    if (on_device) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        Csr csr; SliceStream st; std::string err;
+        if (!prep_on_device(rows, cols, nnz, r, cl, v, csr, st, c->last_prep_times, err))
+            return fail(c, err.find("outside") != std::string::npos || err.find("dimension") != std::string::npos ? HISPMV_EINVAL : HISPMV_EDEVICE, err);
+        double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return add_sparse(c, std::move(csr), t, &st);
+    }
+    Csr csr = coo_to_csr(rows, cols, nnz, r, cl, v);
+    double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return add_sparse(c, std::move(csr), t);
+}
+
 HISPMV_API int hispmv_create_sparse_handle(hispmv_ctx* c, const int32_t* r, const int32_t* cl, const float* v,
                                            int64_t nnz, int32_t rows, int32_t cols) {
     if (!c) return HISPMV_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     if (rows <= 0 || cols <= 0 || nnz < 0 || (nnz > 0 && (!r || !cl || !v))) return fail(c, HISPMV_EINVAL, "bad sparse matrix arguments");
     try {
-        auto t0 = std::chrono::steady_clock::now();
-        Csr csr = coo_to_csr(rows, cols, nnz, r, cl, v);
-        double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return add_sparse(c, std::move(csr), t);
+        return add_from_coo(c, rows, cols, nnz, r, cl, v);
     } catch (const std::out_of_range& ex) { return fail(c, HISPMV_EINVAL, ex.what());
     } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory");
     } catch (const std::exception& ex) { return fail(c, HISPMV_EINVAL, ex.what()); }
@@ -501,11 +522,8 @@ HISPMV_API int hispmv_create_sparse_handle_from_mtx(hispmv_ctx* c, const char* p
     try {
         auto t0 = std::chrono::steady_clock::now();
         Coo coo = read_mtx(path, (MtxFlavor)flavor);
-        auto t1 = std::chrono::steady_clock::now();   // like the reference, file parsing is not "Pre-processing Time"
-        Csr csr = coo_to_csr(coo.rows, coo.cols, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), coo.v.data());
-        (void)t0;
-        double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-        return add_sparse(c, std::move(csr), t);
+        (void)t0;                                     // like the reference, file parsing is not "Pre-processing Time"
+        return add_from_coo(c, coo.rows, coo.cols, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), coo.v.data());
     } catch (const std::runtime_error& ex) { return fail(c, HISPMV_EIO, ex.what());
     } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory");
     } catch (const std::exception& ex) { return fail(c, HISPMV_EINVAL, ex.what()); }
@@ -944,6 +962,26 @@ HISPMV_API int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* r, const i
         auto p = std::make_unique<hispmv_prep>();
         p->csr = coo_to_csr(rows, cols, nnz, r, cl, v);
         p->st = build_stream(p->csr);
+        *out = p.release();
+        return HISPMV_OK;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
+
+HISPMV_API int hispmv_prep_from_coo_device(hispmv_prep** out, int device_id, const int32_t* r, const int32_t* cl, const float* v,
+                                           int64_t nnz, int32_t rows, int32_t cols, double seconds[5]) {
+    if (!out) return HISPMV_EINVAL;
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || nnz < 0 || (nnz > 0 && (!r || !cl || !v))) { g_prep_err = "bad sparse matrix arguments"; return HISPMV_EINVAL; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_prep_err = "no such HIP device"; return HISPMV_EDEVICE; }
+    try {
+        auto p = std::make_unique<hispmv_prep>();
+        DevicePrepTimes t;
+        std::string err;
+        if (!prep_on_device(rows, cols, nnz, r, cl, v, p->csr, p->st, t, err)) {
+            g_prep_err = err;
+            return err.find("outside") != std::string::npos || err.find("dimension") != std::string::npos ? HISPMV_EINVAL : HISPMV_EDEVICE;
+        }
+        if (seconds) { seconds[0] = t.upload; seconds[1] = t.csr_device; seconds[2] = t.offsets_host; seconds[3] = t.stream_device; seconds[4] = t.download; }
         *out = p.release();
         return HISPMV_OK;
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }

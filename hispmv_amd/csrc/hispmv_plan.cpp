@@ -165,13 +165,13 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         // is ~5x cheaper per byte than the HBM stream), and a penalty for fewer than 16 resident wavefronts per CU
         const int waves = c.per_cu * c.threads / 64;
         // a workgroup stages its window BEFORE it works on its slices: with one or two workgroups per CU nothing hides
-        // that phase, so a window as large as the group's own stream (R-MAT scale 20 with 16 slices per workgroup:
-        // 124 KiB staged per 128 KiB of stream, 343 us against 180 us gathering everything through L2) must be amortised
-        // over at least four times its bytes of stream
+        // that phase (~3 us against ~0.4 us per slice; one L2-gathered element costs about 3.3 streamed ones): a window
+        // next to a short group does not pay -- R-MAT scale 20 with 16 slices per workgroup, 124 KiB staged per 128 KiB
+        // of stream and half of the gathers still through L2, ran 343 us against 180 us gathering everything through L2
         const double staged_ratio = (double)staged_blocks * kFragBlock * 4.0 / ((double)n * kSliceElems * 8.0);
-        const double unhidden = c.per_cu == 1 ? 2.0 : c.per_cu == 2 ? 1.0 : 0.3;
+        const double unhidden = (c.per_cu <= 2 ? 2.25 : 0.5) / (double)G;
         const double cost = ((double)staged_blocks + (double)global_elems) / ((double)n * kSliceElems) +
-                            0.2 * staged_ratio + unhidden * std::max(0.0, staged_ratio - 0.25) +
+                            0.2 * staged_ratio + unhidden +
                             0.3 * std::max(0, 16 - waves) / 16.0;
         if (cost < best_cost && cost < 0.8) { best_cost = cost; have = true; chosen = c; chosen_G = G; }
     }

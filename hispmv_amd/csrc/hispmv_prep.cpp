@@ -221,47 +221,51 @@ Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const 
 // ---------------------------------------------------------------------------
 // CSR -> slice stream
 // ---------------------------------------------------------------------------
-SliceStream build_stream(const Csr& m) {
-    SliceStream st;
-    st.rows = m.rows; st.cols = m.cols; st.nnz = m.nnz();
-    const int32_t R = m.rows;
+// Element offset of every row in the stream: every row owns >= 1 element (an empty row gets one zero-valued filler so
+// that "one row end per row" holds and row ids need no list), and -- row-aligned slices -- when every row fits a slice
+// and it costs <= 6 % of the stream, a row that would be cut by a slice boundary starts at the next slice instead and
+// the row before it is extended to the boundary with zero-valued elements (its row end moves to the last of them): no
+// row is cut => no carry chain, no fix-up launch.  Waste ~ half a row per slice: 2.4 % for PFlow_742 (50 per row), too
+// much for rows of hundreds of elements.  O(rows), sequential: shared by the host and the device packer.
+std::vector<int64_t> stream_row_offsets(int32_t R, const int64_t* row_ptr) {
     const int64_t S = kSliceElems;
-    // element offset of each row: every row owns >= 1 element (empty rows get one
-    // zero-valued filler so that "one row end per row" holds and row ids need no list)
     std::vector<int64_t> eoff((size_t)R + 1, 0);
     int64_t max_len = 1, plain = 0;
     for (int32_t i = 0; i < R; ++i) {
-        const int64_t len = std::max<int64_t>(m.row_ptr[(size_t)i + 1] - m.row_ptr[i], 1);
+        const int64_t len = std::max<int64_t>(row_ptr[(size_t)i + 1] - row_ptr[i], 1);
         max_len = std::max(max_len, len);
         plain += len;
     }
-    // Row-aligned slices: when every row fits a slice and it costs little, a row that would be cut by a slice boundary
-    // starts at the next slice instead and the row before it is extended to the boundary with zero-valued elements
-    // (its row end moves to the last of them).  No row is cut => no carry chain, no fix-up launch (~5 us per SpMV).
-    // Waste ~ half a row per slice: 2.4 % for PFlow_742 (50 per row), too much for rows of hundreds of elements.
     bool align = false;
     const char* env_align = std::getenv("HISPMV_ROW_ALIGN");          // "0" switches the alignment off (experiments)
     if (max_len <= S && max_len > 1 && !(env_align && env_align[0] == '0')) {
         int64_t pos = 0;
         for (int32_t i = 0; i < R; ++i) {
-            const int64_t len = std::max<int64_t>(m.row_ptr[(size_t)i + 1] - m.row_ptr[i], 1);
+            const int64_t len = std::max<int64_t>(row_ptr[(size_t)i + 1] - row_ptr[i], 1);
             const int64_t room = S - pos % S;
             if (room < S && len > room) pos += room;
             pos += len;
         }
         align = (pos - plain) * 100 <= 6 * plain;
     }
-    {
-        int64_t pos = 0;
-        for (int32_t i = 0; i < R; ++i) {
-            const int64_t len = std::max<int64_t>(m.row_ptr[(size_t)i + 1] - m.row_ptr[i], 1);
-            const int64_t room = S - pos % S;
-            if (align && room < S && len > room) pos += room;      // row i-1 is extended over [pos, pos + room)
-            eoff[i] = pos;
-            pos += len;
-        }
-        eoff[R] = pos;
+    int64_t pos = 0;
+    for (int32_t i = 0; i < R; ++i) {
+        const int64_t len = std::max<int64_t>(row_ptr[(size_t)i + 1] - row_ptr[i], 1);
+        const int64_t room = S - pos % S;
+        if (align && room < S && len > room) pos += room;      // row i-1 is extended over [pos, pos + room)
+        eoff[i] = pos;
+        pos += len;
     }
+    eoff[R] = pos;
+    return eoff;
+}
+
+SliceStream build_stream(const Csr& m) {
+    SliceStream st;
+    st.rows = m.rows; st.cols = m.cols; st.nnz = m.nnz();
+    const int32_t R = m.rows;
+    const int64_t S = kSliceElems;
+    const std::vector<int64_t> eoff = stream_row_offsets(R, m.row_ptr.data());
     st.n_elems = eoff[R];
     st.n_slices = (st.n_elems + S - 1) / S;
     st.words.assign((size_t)(st.n_slices * S), pack_elem(0.0f, 0, false));

@@ -79,6 +79,9 @@ Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const 
 // Stable per-row sort by column of a CSR whose rows may be unsorted (rows already ascending are left alone).
 void sort_rows_by_column(Csr& m);
 
+// Element offset of every row in the slice stream (fillers for empty rows, row-aligned slices): rows + 1 entries.
+std::vector<int64_t> stream_row_offsets(int32_t rows, const int64_t* row_ptr);
+
 // CSR -> slice stream.
 SliceStream build_stream(const Csr& m);
 

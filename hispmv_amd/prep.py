@@ -75,6 +75,21 @@ def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int) -> Prepa
     return _collect(p)
 
 
+def prep_from_coo_device(coo_rows, coo_cols, coo_values, rows: int, cols: int, device: int = 0):
+    """The same object with both heavy stages computed on the MI355X (hispmv_prep_from_coo_device) -> (Prepared, seconds
+    dict).  Needs a gfx950 device."""
+    r = np.ascontiguousarray(coo_rows, dtype=np.int32)
+    c = np.ascontiguousarray(coo_cols, dtype=np.int32)
+    v = np.ascontiguousarray(coo_values, dtype=np.float32)
+    p = C.c_void_p()
+    secs = (C.c_double * 5)()
+    rc = lib.hispmv_prep_from_coo_device(C.byref(p), int(device), C.c_void_p(r.ctypes.data), C.c_void_p(c.ctypes.data),
+                                         C.c_void_p(v.ctypes.data), r.size, rows, cols, secs)
+    if rc != HISPMV_OK:
+        raise ValueError(lib.hispmv_prep_last_error().decode())
+    return _collect(p), dict(zip(("upload", "csr_device", "offsets_host", "stream_device", "download"), (float(x) for x in secs)))
+
+
 def prep_from_mtx(path, flavor: int = 0) -> Prepared:
     p = C.c_void_p()
     rc = lib.hispmv_prep_from_mtx(C.byref(p), str(path).encode(), int(flavor))

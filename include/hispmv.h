@@ -167,6 +167,13 @@ typedef struct hispmv_prep hispmv_prep;
 int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* coo_rows, const int32_t* coo_cols,
                          const float* coo_values, int64_t nnz, int32_t rows, int32_t cols);
 int hispmv_prep_from_mtx(hispmv_prep** out, const char* mtx_path, int flavor);
+/* The same object with COO -> CSR (stable radix sort) and CSR -> slice stream computed ON THE DEVICE `device_id`
+ * (retires the hotspot of common/src/spmv-helper.cpp:139-227): CSR, words, headers and split-row list
+ * are byte-identical to hispmv_prep_from_coo's.  seconds (may be NULL) = {upload, COO->CSR on the device, row offsets on
+ * the host, stream on the device, downloads}.  create_sparse_handle uses this path from 2 M entries
+ * (HISPMV_PREP=host|device|auto). */
+int hispmv_prep_from_coo_device(hispmv_prep** out, int device_id, const int32_t* coo_rows, const int32_t* coo_cols,
+                                const float* coo_values, int64_t nnz, int32_t rows, int32_t cols, double seconds[5]);
 void hispmv_prep_free(hispmv_prep* p);
 const char* hispmv_prep_last_error(void);
 /* dims[0..7] = rows, cols, nnz, n_elems, n_slices, slice_elems, n_split_rows, stream_bytes */

@@ -53,6 +53,8 @@ def _load():
     lib.orc_cpu_bench_spmv.restype = C.c_double
     lib.orc_cpu_bench_gemv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _ip]
     lib.orc_cpu_bench_gemv.restype = C.c_double
+    lib.orc_print_error_stats.argtypes = [C.c_int64, _p, C.c_int64, _p, C.c_char_p, C.c_int]
+    lib.orc_print_error_stats.restype = C.c_int
     lib.refpack_create.argtypes = [C.c_int] * 8
     lib.refpack_create.restype = _p
     lib.refpack_free.argtypes = [_p]
@@ -199,6 +201,14 @@ def mkl_spmv(row_ptr, col_idx, vals, cols, x, y0, alpha, beta, reps=1, threads=0
     if t < 0:
         return None
     return t, nt.value, y
+
+
+def print_error_stats(cpu_ref, fpga_out):
+    """The text HiSpmvHandle::printErrorStats would print (spmv-helper.cpp:835-895), or None where it throws / aborts."""
+    a, b = _c(cpu_ref, np.float32), _c(fpga_out, np.float32)
+    buf = C.create_string_buffer(1 << 16)
+    n = lib.orc_print_error_stats(a.size, _ptr(a), b.size, _ptr(b), buf, len(buf))
+    return None if n < 0 else buf.value.decode()
 
 
 def cpu_bench_spmv(row_ptr, col_idx, vals, cols, mode, threads, budget_s, max_reps=200):

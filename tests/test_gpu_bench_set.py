@@ -177,9 +177,14 @@ def test_model_test_layers_full_size(batch):
             for k in range(batch):
                 check_y(f"C4:layer{idx}:{kind}:b{batch}:v{k}", out[k * rows:(k + 1) * rows], rp, ci, va, cols,
                         x[k * cols:(k + 1) * cols], bias, 1.0, 1.0, mkl=(k == 0))
-            if batch > 1:       # a batched pass gives every vector the bits of its single-vector run
+            if batch > 1:
+                # a batched pass gives every vector the bits of its single-vector run with the fix-up carry variant; a matrix
+                # whose single launch merges its cut rows in-kernel (look-back) may differ in the last bit of those rows
                 one = h.linear(idx, x[:cols], bias)
-                assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
+                if kind == "dense" or not h.matrix_info(idx)["carry_lookback"]:
+                    assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
+                else:
+                    assert np.allclose(one, out[:rows], rtol=2e-6, atol=0)
     finally:
         h.close()
 
