@@ -32,6 +32,7 @@ class MatrixInfo(C.Structure):
         ("block_threads", C.c_int32), ("group_slices", C.c_int32), ("lds_bytes", C.c_int32), ("col_tiles", C.c_int32),
         ("carry_lookback", C.c_int32), ("col_tile_width", C.c_int32),
         ("col_tile_base", C.c_int32), ("compact_slices", C.c_int32),
+        ("format", C.c_int32), ("tts_lines_per_gather", C.c_float),
     ]
 
 
@@ -43,6 +44,8 @@ _f32p = C.POINTER(C.c_float)
 
 # name -> (restype, argtypes); every symbol include/hispmv.h declares.
 SIGNATURES = {
+    "hispmv_prep_build_tts": (C.c_int, [_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "hispmv_prep_tts_array": (C.c_void_p, [_p, C.c_int]),
     "hispmv_version": (C.c_char_p, []),
     "hispmv_free_failures": (C.c_int64, []),
     "hispmv_boundary_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -22,6 +22,7 @@
 #include "hispmv_plan.h"
 #include "hispmv_prep.h"
 #include "hispmv_prep_device.h"
+#include "hispmv_tts.h"
 
 #define HISPMV_API extern "C" __attribute__((visibility("default")))
 
@@ -45,12 +46,17 @@ struct Matrix {
         std::vector<FixEntry> fix_short, fix_long;
         LaunchPlan plan;
         DeviceStream dstream;                      // the planned stream in its device layout (compact / wide groups)
+        bool is_tts = false;                       // the part is a transposed tile stream (hispmv_tts.h) instead of a slice stream
+        TtsStream tts;                             //   host side (released after upload)
+        TtsDeviceMatrix tdev;                      //   device side
         SpmvDeviceMatrix dev;                      // device side
     };
     std::vector<Part> parts;
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0, compact_slices = 0;
     int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
+    int format = 0;             // 0 slice stream, 1 transposed tile stream
+    double tts_lines_per_gather = 0;
     bool l2_tiles = false;      // the column tiles gather x through L2 (L2-sized tiles): pinned to XCD subsets in a batch call
     float* d_dense = nullptr;
     // column tiles t > 0 write alpha*A_t*x here (tile t, vector v of a batched pass: d_ypart + ((t-1)*kMaxBatch + v)*rows);
@@ -67,6 +73,12 @@ struct hispmv_ctx {
     bool dense_overlay = false, pre_accumulator = false, row_dist_net = false;
     hipStream_t stream = nullptr;
     hipStream_t user_stream = nullptr;   // last caller-supplied stream a launch went to (hispmv_synchronize waits for it too)
+    // hispmv_spmv_device_batch: the independent main launches of a call (tile streams, slice classes) go to the caller's
+    // stream and to these side streams, forked from / joined to it with events, so that the tail of one grid overlaps the
+    // head of the next (HISPMV_BATCH_STREAMS=1 keeps everything on one stream)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int batch_streams = 2;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.0f;
     std::mutex mu;
@@ -87,7 +99,9 @@ struct hispmv_ctx {
     // hispmv_spmv_device_batch: the launches of one call signature (handles, vectors, beta == 0 or not) with their device
     // tables, built on the first call and replayed afterwards
     struct BatchLaunch {
-        int kind = 0;                                   // 0 slice kernels of one workgroup size, 1 fix-up of cut rows, 2 merge of column-tile partial vectors
+        int kind = 0;                                   // 0 slice kernels of one workgroup size, 1 fix-up of cut rows, 2 merge of column-tile
+                                                        // partial vectors, 3 transposed tile streams
+        std::vector<TtsEntry> tts;                      // kind 3
         std::vector<const SpmvDeviceMatrix*> parts;     // kinds 0, 1
         std::vector<float*> ys;                         // kind 1: where each part's cut rows live (y or a partial vector)
         std::vector<int32_t> rows;                      // kind 2
@@ -107,6 +121,10 @@ struct hispmv_ctx {
     // 2 M entries (HISPMV_PREP=host|device|auto); both give the same stream byte for byte
     int prep_mode = 2;
     DevicePrepTimes last_prep_times;
+    // device format of matrices whose plan gathers x through L2: 0 slice stream always, 1 transposed tile stream whenever
+    // the plan has no window, 2 auto = transposed tile stream when its gathers touch <= 32 cache lines of x per wave
+    // instruction (HISPMV_FORMAT=slices|tts|auto)
+    int format_mode = 2;
     int n_cus = 256;
 };
 
@@ -114,6 +132,7 @@ struct hispmv_prep {
     Csr csr;
     SliceStream st;
     LaunchPlan plan;
+    TtsStream tts;
 };
 
 namespace {
@@ -272,6 +291,27 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         cmin = (int32_t)qlo; cmax = (int32_t)qhi;
     }
     const int32_t used = cmax >= cmin ? cmax - (cmin & ~63) + 1 : 0;
+    // Scattered columns (no window pays): the transposed tile stream, when sorting a row tile's elements by column brings
+    // several of them onto each cache line of x (hispmv_tts.h).  Takes the place of the L2-sized column tiles below.
+    if (whole.lds_floats == 0 && c->format_mode != 0 && nnz_all >= 64 * 1024) {
+        TtsStream ts = build_tts(csr);
+        if (c->format_mode == 1 || ts.lines_per_gather <= 32.0) {
+            Matrix::Part& p = m->parts[0];
+            p.is_tts = true;
+            p.tts = std::move(ts);
+            p.st = SliceStream{}; p.dstream = DeviceStream{}; p.fix_short = {}; p.fix_long = {};
+            m->format = 1; m->tts_lines_per_gather = p.tts.lines_per_gather;
+            m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = 0;
+            m->device_bytes = p.tts.bytes();
+            m->plan_threads = kTtsThreads; m->plan_group = 0; m->plan_lds = 0;
+            m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            csr = Csr{};
+            if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
+            c->arena_used += m->device_bytes;
+            c->mats.push_back(std::move(m));
+            return (int)c->mats.size() - 1;
+        }
+    }
     // (a window that leaves more than a tenth of the gathers to L2 counts as "does not fit" here)
     const bool spilling = whole.lds_floats > 0 && whole.global_elems * 10 > m->parts[0].st.n_slices * (int64_t)kSliceElems;
     if (used > 0 && (whole.lds_floats == 0 || spilling)) {
@@ -343,6 +383,11 @@ int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bia
         if (e != hipSuccess) return hip_fail(c, e, "launch_gemv");
         return HISPMV_OK;
     }
+    if (m.format == 1) {
+        hipError_t e = launch_tts(m.parts[0].tdev, d_x, d_bias, d_y, alpha, beta, s);
+        if (e != hipSuccess) return hip_fail(c, e, "launch_tts");
+        return HISPMV_OK;
+    }
     for (size_t t = 0; t < m.parts.size(); ++t) {
         // column tile 0 computes alpha*A_0*x + beta*bias into y; tile t > 0 writes alpha*A_t*x into its partial vector
         hipError_t e = (t == 0) ? launch_spmv(m.parts[t].dev, d_x, d_bias, d_y, alpha, beta, s)
@@ -364,6 +409,13 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
     if (m.dense) {
         hipError_t e = launch_gemv_batched(m.d_dense, m.rows, m.cols, vecs, d_x, d_bias, d_y, alpha, beta, s);
         if (e != hipSuccess) return hip_fail(c, e, "launch_gemv_batched");
+        return HISPMV_OK;
+    }
+    if (m.format == 1) {          // transposed tile stream: one launch per vector (same bits as a single-vector call)
+        for (int64_t k = 0; k < vecs; ++k) {
+            const int rc = launch_matrix(c, m, d_x + k * m.cols, d_bias, d_y + k * m.rows, alpha, beta, s);
+            if (rc != HISPMV_OK) return rc;
+        }
         return HISPMV_OK;
     }
     int64_t k = 0;
@@ -454,6 +506,14 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
+    if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) c->batch_streams = std::max(1, std::min(3, std::atoi(env)));
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate(side)");
+        if ((e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(join)");
+    }
+    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(fork)");
+    if (const char* env = std::getenv("HISPMV_FORMAT"))
+        c->format_mode = !std::strcmp(env, "slices") ? 0 : !std::strcmp(env, "tts") ? 1 : 2;
     if (const char* env = std::getenv("HISPMV_PREP"))
         c->prep_mode = !std::strcmp(env, "host") ? 0 : !std::strcmp(env, "device") ? 1 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -472,6 +532,8 @@ HISPMV_API void hispmv_destroy(hispmv_ctx* c) {
     host_free(c->h_err);
     host_free(c->h_stage);
     free_batch_plans(c);
+    for (int i = 0; i < 2; ++i) { if (c->side[i]) (void)hipStreamDestroy(c->side[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -586,6 +648,25 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             const float* d = nullptr;
             if ((rc = upload(c, m, m.dense_host.data(), m.dense_host.size(), &d)) != HISPMV_OK) return rc;
             m.d_dense = const_cast<float*>(d);
+        } else if (m.format == 1) {
+            Matrix::Part& p = m.parts[0];
+            TtsStream& ts = p.tts;
+            const uint8_t* dw = nullptr; const int32_t* dcb = nullptr; const uint16_t* dfl = nullptr; const int32_t* dci = nullptr;
+            const TtsTile* dt = nullptr; const TtsBlock* db = nullptr;
+            if ((rc = upload(c, m, ts.words.data(), ts.words.size(), &dw)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, ts.col_base.data(), ts.col_base.size(), &dcb)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, ts.flags.data(), ts.flags.size(), &dfl)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, ts.chunk_info.data(), ts.chunk_info.size(), &dci)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, ts.tiles.data(), ts.tiles.size(), &dt)) != HISPMV_OK) return rc;
+            if ((rc = upload(c, m, ts.blocks.data(), ts.blocks.size(), &db)) != HISPMV_OK) return rc;
+            TtsDeviceMatrix& d = p.tdev;
+            d.words = dw; d.col_base = dcb; d.flags = dfl; d.chunk_info = (const int2*)dci; d.tiles = (const int4*)dt; d.blocks = (const int4*)db;
+            d.n_tiles = (int32_t)ts.tiles.size(); d.rows = m.rows; d.cols = m.cols;
+            d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = kTtsThreads;
+            d.staging_floats = kTtsMaxSlots + 64;                 // (the dummy slot of padding words sits behind the last real one)
+            if (((size_t)d.acc_floats + d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            p.tts = TtsStream{};
         } else {
             for (auto& p : m.parts) {
                 const uint8_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
@@ -763,9 +844,35 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         return r.t == 0 ? d_y[r.i] : m.d_ypart + (r.t - 1) * (size_t)kMaxBatch * m.rows;
     };
     const bool pin = !std::getenv("HISPMV_NO_XCD_PIN");
+    auto upload_table0 = [&](hispmv_ctx::BatchLaunch& l, const void* host, size_t bytes) -> int {
+        HIP_TRY(c, hipMalloc(&l.d_table, bytes));
+        HIP_TRY(c, hipMemcpy(l.d_table, host, bytes, hipMemcpyHostToDevice));
+        return HISPMV_OK;
+    };
+    {   // transposed tile streams: their row tiles share one grid of 1024-thread workgroups
+        hispmv_ctx::BatchLaunch l;
+        l.kind = 3;
+        for (int i = 0; i < n; ++i) {
+            Matrix& m = *c->mats[idx[i]];
+            if (m.dense || m.format != 1) continue;
+            l.tts.push_back(TtsEntry{m.parts[0].tdev, d_x[i], bias[i], d_y[i], beta, 0});
+            if ((int)l.tts.size() == kMultiMax) {
+                plan.launches.push_back(std::move(l));
+                const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().tts.data(), plan.launches.back().tts.size() * sizeof(TtsEntry));
+                if (rc0 != HISPMV_OK) return rc0;
+                l = hispmv_ctx::BatchLaunch{};
+                l.kind = 3;
+            }
+        }
+        if (!l.tts.empty()) {
+            plan.launches.push_back(std::move(l));
+            const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().tts.data(), plan.launches.back().tts.size() * sizeof(TtsEntry));
+            if (rc0 != HISPMV_OK) return rc0;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const Matrix& m = *c->mats[idx[i]];
-        if (m.dense) continue;
+        if (m.dense || m.format == 1) continue;
         if (m.l2_tiles && pin) {                 // the L2-sized column tiles of a matrix: one item, pinned to XCD subsets
             Item it{{}, m.parts[0].dev.block_threads, 0};
             for (size_t t = 0; t < m.parts.size(); ++t) { it.refs.push_back(Ref{i, t}); it.slices += m.parts[t].dev.n_slices; }
@@ -837,7 +944,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
     };
     for (int i = 0; i < n; ++i) {                               // merge of the column-tile partial vectors
         Matrix& m = *c->mats[idx[i]];
-        if (m.dense || m.parts.size() < 2) continue;
+        if (m.dense || m.format == 1 || m.parts.size() < 2) continue;
         merges.push_back(MultiMergeEntry{d_y[i], m.d_ypart, (long long)kMaxBatch * m.rows, (int32_t)m.parts.size() - 1, m.rows});
         merge_rows.push_back(m.rows);
         if ((int)merges.size() == kMultiMax && (rc = flush_merges()) != HISPMV_OK) return rc;
@@ -893,13 +1000,34 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
         }
         plan = &c->batch_plans.back();
     }
+    // main launches (kinds 0 and 3) are independent of each other: spread over the caller's stream and the side streams;
+    // the fix-up and merge launches follow on the caller's stream behind a join
+    int n_main = 0;
+    for (const auto& l : plan->launches) n_main += l.kind == 0 || l.kind == 3;
+    const int lanes = std::min(c->batch_streams, n_main);
+    if (lanes > 1) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        for (int i = 0; i + 1 < lanes; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+    }
+    int k_main = 0;
+    bool joined = lanes <= 1;
     for (const auto& l : plan->launches) {
         hipError_t e = hipSuccess;
-        if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, s);
-        else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, s);
-        else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, s);
-        if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : "launch_merge_multi");
+        const bool is_main = l.kind == 0 || l.kind == 3;
+        hipStream_t ls = s;
+        if (is_main && lanes > 1) { const int lane = k_main++ % lanes; ls = lane == 0 ? s : c->side[lane - 1]; }
+        if (!is_main && !joined) {
+            for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
+            joined = true;
+        }
+        if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
+        else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), (const TtsEntry*)l.d_table, alpha, ls);
+        else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
+        else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
+        if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : "launch_merge_multi");
     }
+    if (!joined)
+        for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
     return HISPMV_OK;
 }
 
@@ -947,6 +1075,7 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->block_threads = m.plan_threads; out->group_slices = m.plan_group; out->lds_bytes = m.plan_lds * 4;
     out->col_tiles = (int32_t)m.parts.size();
     out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width; out->col_tile_base = m.col_tile_base; out->compact_slices = (int32_t)std::min<int64_t>(m.compact_slices, INT32_MAX);
+    out->format = m.format; out->tts_lines_per_gather = (float)m.tts_lines_per_gather;
     return HISPMV_OK;
 }
 
@@ -1028,6 +1157,30 @@ HISPMV_API int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[
 }
 HISPMV_API const int32_t* hispmv_prep_groups(const hispmv_prep* p) { return (const int32_t*)p->plan.groups.data(); }
 HISPMV_API const int32_t* hispmv_prep_frags(const hispmv_prep* p) { return (const int32_t*)p->plan.frags.data(); }
+
+HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int64_t counts[8], double* lines_per_gather) {
+    if (!p || !counts) return HISPMV_EINVAL;
+    try {
+        p->tts = build_tts(p->csr, target_tile_elems);
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+    const TtsStream& t = p->tts;
+    counts[0] = (int64_t)t.tiles.size(); counts[1] = (int64_t)t.blocks.size(); counts[2] = (int64_t)t.col_base.size();
+    counts[3] = (int64_t)t.chunk_info.size() / 2; counts[4] = t.n_fillers; counts[5] = t.n_pad_words; counts[6] = t.max_rows; counts[7] = t.max_slots;
+    if (lines_per_gather) *lines_per_gather = t.lines_per_gather;
+    return HISPMV_OK;
+}
+HISPMV_API const void* hispmv_prep_tts_array(const hispmv_prep* p, int which) {
+    if (!p) return nullptr;
+    switch (which) {
+        case 0: return p->tts.words.data();
+        case 1: return p->tts.col_base.data();
+        case 2: return p->tts.flags.data();
+        case 3: return p->tts.chunk_info.data();
+        case 4: return p->tts.tiles.data();
+        case 5: return p->tts.blocks.data();
+        default: return nullptr;
+    }
+}
 
 HISPMV_API const int64_t* hispmv_prep_csr_row_ptr(const hispmv_prep* p) { return p->csr.row_ptr.data(); }
 HISPMV_API const int32_t* hispmv_prep_csr_col(const hispmv_prep* p) { return p->csr.col.data(); }

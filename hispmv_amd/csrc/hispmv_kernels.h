@@ -32,6 +32,24 @@ struct SpmvDeviceMatrix {
     int32_t rows = 0, cols = 0;
 };
 
+// Transposed tile stream (hispmv_tts.h): device tables of one matrix.
+struct TtsDeviceMatrix {
+    const void* words = nullptr;        // per column-order slice: 1024 x fp32, then 1024 x {col_off:16 | slot:16}
+    const int32_t* col_base = nullptr;  // per slice
+    const uint16_t* flags = nullptr;    // per row-major chunk: 64 x u16 row-end bits
+    const int2* chunk_info = nullptr;   // per chunk: {rows ending before it, chain_len}
+    const int4* tiles = nullptr;        // {row0, n_rows, block_begin, n_blocks}
+    const int4* blocks = nullptr;       // 2 x int4 per block: {slice_begin, n_slices, chunk_begin, n_chunks}, {n_slots, 0, 0, 0}
+    int32_t n_tiles = 0, rows = 0, cols = 0;
+    int32_t acc_floats = 0, staging_floats = 0;    // LDS: accumulators (max rows of a tile), staging (max slots of a block + dummy)
+    int32_t threads = 512;                         // workgroup size (hispmv_tts.h: kTtsThreads)
+};
+struct TtsEntry {                       // multi-matrix launch: one per matrix
+    TtsDeviceMatrix m;
+    const float* x; const float* bias; float* y;
+    float beta; int32_t pad;
+};
+
 struct LookbackArgs {
     unsigned long long* gran;
     unsigned long long* ticket;
@@ -98,6 +116,11 @@ hipError_t launch_merge_parts(float* y, const float* parts, int n_parts, int64_t
 hipError_t launch_merge_multi(const int32_t* rows, int n, const MultiMergeEntry* d_table, hipStream_t stream);
 hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const* ys, int n, const MultiFixEntry* d_fix_table,
                               float alpha, hipStream_t stream);
+
+// Transposed tile stream: y = alpha*A*x + beta*bias in ONE launch (one workgroup of 1024 threads per row tile; no carry
+// buffers, no fix-up launch); launch_tts_multi: the tiles of `n` matrices in one grid (d_table: device copy of TtsEntry).
+hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream);
+hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_table, float alpha, hipStream_t stream);
 
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,

@@ -61,6 +61,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return i2f(__builtin_amdgcn_readlane(f2i(v), 63));   // lane 63 holds the total
 }
 
+constexpr int kTtsChunkSlots = 1024;   // hispmv_tts.h: kTtsChunk
 constexpr int kLookbackSpinMax = 1 << 22;   // ~seconds; a wait this long means a lost launch, not contention
 
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
@@ -154,6 +155,11 @@ __device__ __forceinline__ float4 load_float4(const float4* p) {
     return float4{v.x, v.y, v.z, v.w};
 }
 __device__ __forceinline__ void store_float(float* p, float v) { *(HISPMV_GLOBAL float*)p = v; }
+__device__ __forceinline__ int2 load_int2(const int2* p) {
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    const i2v v = *(const HISPMV_GLOBAL i2v*)p;
+    return int2{v.x, v.y};
+}
 
 // A slice as it arrives: per step 4 values and 4 metas per lane (compact: 4 x u16 in a uint2; wide: 4 x u32).
 template <bool COMPACT> struct SliceRaw;
@@ -1011,6 +1017,211 @@ hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const
             hipLaunchKernelGGL(spmv_fixup_long_kernel, dim3((m.n_fix_long + 3) / 4), dim3(256), 0, stream,
                                m.fix_long, m.n_fix_long, m.carry, ys[i], alpha, 0LL, 0LL);
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Transposed tile stream (hispmv_tts.h): one workgroup of 16 wavefronts per row tile.
+//   LDS: [row accumulators of the tile][staging: products of the block in flight, by row-major slot][chunk tails]
+//   per block  phase A: the block's words in COLUMN order, 1024 per slice (values + {col_off:16|slot:16} metas, one
+//                       dwordx4 each per lane and step, requested one slice ahead): x gathered through a buffer
+//                       descriptor with the slice's column base as scalar offset -- neighbouring lanes read
+//                       neighbouring columns, a few cache lines per gather --, product -> staging[slot]
+//              barrier
+//              phase B: the staging in ROW-MAJOR order, 1024 slots per chunk (ds_read_b128), row ends from 16 flag bits
+//                       per lane, scan_step as in the slice kernel, acc[row] += total by the lane holding the row end
+//                       (rows are distinct inside a block pass); the open tail of a chunk goes to tails[chunk]
+//              barrier, then one wavefront adds the tails of rows cut by chunk boundaries (in chunk order)
+//   end: y = alpha*acc + beta*bias, coalesced.  No atomics, fixed summation order.
+// ---------------------------------------------------------------------------
+struct TtsSlice { uint4 v[kSliceSteps]; uint4 m[kSliceSteps]; };
+__device__ __forceinline__ void tts_request(TtsSlice& s, const char* words, int slice, int lane) {
+    const uint4* pv = (const uint4*)(words + (size_t)slice * (kSliceElems * 8)) + lane;
+#pragma unroll
+    for (int j = 0; j < kSliceSteps; ++j) s.v[j] = load_words(pv + j * 64);
+#pragma unroll
+    for (int j = 0; j < kSliceSteps; ++j) s.m[j] = load_words(pv + 256 + j * 64);
+}
+
+template <bool HAS_BETA>
+__device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const float* __restrict__ x, const float* bias, float* y,
+                                              float alpha, float beta, int tile_index) {
+    extern __shared__ float xs[];
+    float* const acc = xs;
+    float* const staging = xs + M.acc_floats;
+    float* const tails = staging + M.staging_floats;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    constexpr int kE = kSliceSteps * kLaneElems;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, M.cols * 4, 0x00020000);
+    const char* const words = (const char*)M.words;
+    const int4 tile = load_int4(M.tiles + tile_index);
+    const int row0 = tile.x, n_rows = tile.y, block_begin = tile.z, n_blocks = tile.w;
+
+    // the first slice of the first block is requested before anything else
+    int4 blk = load_int4(M.blocks + 2 * (size_t)block_begin);
+    TtsSlice w;
+    int cb = 0;
+    if (n_blocks > 0 && wave < blk.y) {
+        tts_request(w, words, blk.x + wave, lane);
+        cb = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave);
+    }
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+
+    for (int b = 0; b < n_blocks; ++b) {
+        const int slice_begin = __builtin_amdgcn_readfirstlane(blk.x), n_slices = __builtin_amdgcn_readfirstlane(blk.y);
+        const int chunk_begin = __builtin_amdgcn_readfirstlane(blk.z), n_chunks = __builtin_amdgcn_readfirstlane(blk.w);
+        int4 nxt = int4{0, 0, 0, 0};
+        if (b + 1 < n_blocks) nxt = load_int4(M.blocks + 2 * (size_t)(block_begin + b + 1));
+        // ---- phase A: column order --------------------------------------------------------------------------------
+        for (int s = wave; s < n_slices; s += n_waves) {
+            const int base = __builtin_amdgcn_readfirstlane(cb) << 2;
+            float xv[kE];
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                xv[4 * j + 0] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].x >> 16) << 2, base, 0));
+                xv[4 * j + 1] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].y >> 16) << 2, base, 0));
+                xv[4 * j + 2] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].z >> 16) << 2, base, 0));
+                xv[4 * j + 3] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].w >> 16) << 2, base, 0));
+            }
+            float p[kE];
+            unsigned slot[kE];
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                p[4 * j + 0] = i2f((int)w.v[j].x) * xv[4 * j + 0]; slot[4 * j + 0] = w.m[j].x & 0xffffu;
+                p[4 * j + 1] = i2f((int)w.v[j].y) * xv[4 * j + 1]; slot[4 * j + 1] = w.m[j].y & 0xffffu;
+                p[4 * j + 2] = i2f((int)w.v[j].z) * xv[4 * j + 2]; slot[4 * j + 2] = w.m[j].z & 0xffffu;
+                p[4 * j + 3] = i2f((int)w.v[j].w) * xv[4 * j + 3]; slot[4 * j + 3] = w.m[j].w & 0xffffu;
+            }
+#pragma unroll
+            for (int i = 0; i < kE; ++i) asm volatile("" : "+v"(p[i]));
+            asm volatile("" ::: "memory");
+            // the next slice of this wavefront: in this block, or its first one in the next block (in flight across phase B)
+            if (s + n_waves < n_slices) {
+                tts_request(w, words, slice_begin + s + n_waves, lane);
+                cb = *(const HISPMV_GLOBAL int*)(M.col_base + slice_begin + s + n_waves);
+            } else if (wave < nxt.y) {
+                tts_request(w, words, nxt.x + wave, lane);
+                cb = *(const HISPMV_GLOBAL int*)(M.col_base + nxt.x + wave);
+            }
+#pragma unroll
+            for (int i = 0; i < kE; ++i) staging[slot[i]] = p[i];
+        }
+        if (wave >= n_slices && wave < nxt.y) {     // a wavefront without a slice in this block still prefetches for the next
+            tts_request(w, words, nxt.x + wave, lane);
+            cb = *(const HISPMV_GLOBAL int*)(M.col_base + nxt.x + wave);
+        }
+        __syncthreads();
+        // ---- phase B: row-major order -----------------------------------------------------------------------------
+        for (int c = wave; c < n_chunks; c += n_waves) {
+            const int2 ci = load_int2(M.chunk_info + chunk_begin + c);
+            int row = __builtin_amdgcn_readfirstlane(ci.x);
+            const unsigned ends = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + c) * 64 + lane);
+            const float4* st4 = (const float4*)(staging + c * kTtsChunkSlots) + lane;
+            float carry_step = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                const float4 q = st4[j * 64];
+                const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
+                const unsigned e = (ends >> (4 * j)) & 0xfu;
+                int below = 0, total = 0;
+#pragma unroll
+                for (int k = 0; k < kLaneElems; ++k) {
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64((e >> k) & 1u);
+                    below += lanes_below(mk);
+                    total += __builtin_popcountll(mk);
+                }
+                float tj[kLaneElems];
+                scan_step(pj, e, carry_step, tj);
+                int r = row + below;
+#pragma unroll
+                for (int k = 0; k < kLaneElems; ++k) {
+                    if (e & (1u << k)) acc[r] = acc[r] + tj[k];
+                    r += (e >> k) & 1u;
+                }
+                row += total;
+            }
+            if (lane == 0) tails[c] = carry_step;
+        }
+        __syncthreads();
+        // rows cut by a chunk boundary: the chunk that holds the row end added its own part; the tails of the chunks
+        // before it follow here, in chunk order (one lane per chunk; a block has at most 28 chunks)
+        if (wave == 0 && lane < n_chunks) {
+            const int2 ci = load_int2(M.chunk_info + chunk_begin + lane);
+            if (ci.y > 0) {
+                float s = 0.0f;
+                for (int k = lane - ci.y; k < lane; ++k) s += tails[k];
+                acc[ci.x] = acc[ci.x] + s;
+            }
+        }
+        blk = nxt;
+        // (the next phase A writes staging only; tails and acc are next touched behind the barrier that follows it)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) {
+        const float t = acc[i];
+        if (HAS_BETA) *(HISPMV_GLOBAL float*)(y + row0 + i) = alpha * t + beta * *(const HISPMV_GLOBAL float*)(bias + row0 + i);
+        else *(HISPMV_GLOBAL float*)(y + row0 + i) = alpha * t;
+    }
+}
+
+template <bool HAS_BETA>
+__global__ __launch_bounds__(1024) void spmv_tts_kernel(TtsDeviceMatrix M, const float* __restrict__ x, const float* bias, float* y,
+                                                        float alpha, float beta) {
+    tts_tile_body<HAS_BETA>(M, x, bias, y, alpha, beta, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
+    int k = 0;
+#pragma unroll 1
+    while (k + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[k + 1]) ++k;
+    const TtsEntry e = table[k];          // (once per workgroup; every load in the body is cast to the global address space)
+    if (e.beta != 0.0f) tts_tile_body<true>(e.m, e.x, e.bias, e.y, alpha, e.beta, (int)(blockIdx.x - prefix.begin[k]));
+    else tts_tile_body<false>(e.m, e.x, e.y, e.y, alpha, 0.0f, (int)(blockIdx.x - prefix.begin[k]));
+}
+
+static size_t tts_lds_bytes(const TtsDeviceMatrix& m) { return ((size_t)m.acc_floats + (size_t)m.staging_floats + 64) * sizeof(float); }
+
+hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (m.n_tiles <= 0) return hipSuccess;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        raised = true;
+    }
+    const size_t lds = tts_lds_bytes(m);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    if (beta != 0.0f) hipLaunchKernelGGL(spmv_tts_kernel<true>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, bias, y, alpha, beta);
+    else hipLaunchKernelGGL(spmv_tts_kernel<false>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, y, y, alpha, beta);
+    return hipGetLastError();
+}
+
+hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_table, float alpha, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    if (n > kMultiMax) return hipErrorInvalidValue;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        raised = true;
+    }
+    MultiPrefix px{};
+    px.n = n;
+    long long g = 0;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        px.begin[i] = g; px.first[i] = (uint8_t)i; px.tiles[i] = 1;
+        g += entries[i].m.n_tiles;
+        lds = std::max(lds, tts_lds_bytes(entries[i].m));
+    }
+    px.begin[n] = g;
+    if (g > 0x7fffffffLL || lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    if (g > 0) hipLaunchKernelGGL(spmv_tts_multi_kernel, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     return hipGetLastError();
 }
 

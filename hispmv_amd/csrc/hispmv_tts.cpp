@@ -1,0 +1,206 @@
+// hispmv_tts.cpp -- packer of the transposed tile stream (hispmv_tts.h).  Host-only, OpenMP over the row tiles.
+#include "hispmv_tts.h"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+namespace hispmv {
+
+namespace {
+
+struct TileOut {
+    std::vector<TtsBlock> blocks;            // slice_begin / chunk_begin relative to the tile
+    std::vector<uint8_t> words;
+    std::vector<int32_t> col_base;
+    std::vector<uint16_t> flags;
+    std::vector<int32_t> chunk_info;
+    int64_t fillers = 0, pads = 0;
+    double lines = 0; int64_t gathers = 0;
+    int max_slots = 0;
+};
+
+struct Elem { int32_t col; int32_t row; float val; };     // row: tile-local
+
+// One block: elements [e0, e1) of the tile's column-sorted list.
+void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, TileOut& out, std::vector<int32_t>& cnt,
+                std::vector<int32_t>& start, std::vector<uint32_t>& slot_of) {
+    // row-major order of the block: rows ascending, inside a row the elements in column order (the order of `el`), a row
+    // without elements in this block gets one filler slot
+    std::fill(cnt.begin(), cnt.begin() + n_rows, 0);
+    for (size_t i = e0; i < e1; ++i) cnt[(size_t)el[i].row]++;
+    int32_t pos = 0, fillers = 0;
+    for (int r = 0; r < n_rows; ++r) { start[(size_t)r] = pos; if (cnt[(size_t)r] == 0) { ++fillers; pos += 1; } else pos += cnt[(size_t)r]; }
+    const int32_t n_slots = pos;
+    if (n_slots > kTtsMaxSlots) throw std::logic_error("internal: TTS block exceeds its slot budget");
+    const int32_t n_chunks = (n_slots + kTtsChunk - 1) / kTtsChunk;
+    TtsBlock b{};
+    b.slice_begin = (int32_t)out.col_base.size();
+    b.chunk_begin = (int32_t)(out.chunk_info.size() / 2);
+    b.n_chunks = n_chunks; b.n_slots = n_slots;
+    // row-end flags and chunk table
+    const size_t f0 = out.flags.size();
+    out.flags.resize(f0 + (size_t)n_chunks * 64, 0);
+    std::vector<int32_t> ends_before((size_t)n_chunks + 1, 0);
+    auto set_end = [&](int32_t slot) {
+        const int32_t c = slot / kTtsChunk, s = slot % kTtsChunk;
+        const int j = s / 256, l = (s % 256) / 4, k = s % 4;
+        out.flags[f0 + (size_t)c * 64 + (size_t)l] |= (uint16_t)(1u << (4 * j + k));
+        ends_before[(size_t)c + 1]++;
+    };
+    for (int r = 0; r < n_rows; ++r) set_end(start[(size_t)r] + std::max(cnt[(size_t)r], 1) - 1);
+    for (int c = 0; c < n_chunks; ++c) ends_before[(size_t)c + 1] += ends_before[(size_t)c];
+    for (int c = 0; c < n_chunks; ++c) {
+        const int32_t row_base = ends_before[(size_t)c];        // first row that ends in this chunk (when one does)
+        int32_t chain = 0;
+        if (ends_before[(size_t)c + 1] > row_base && row_base < n_rows && start[(size_t)row_base] < c * kTtsChunk)
+            chain = c - start[(size_t)row_base] / kTtsChunk;
+        out.chunk_info.push_back(row_base);
+        out.chunk_info.push_back(chain);
+    }
+    // slots of the elements (column order -> row-major position); cnt[] becomes the running fill of each row
+    std::fill(cnt.begin(), cnt.begin() + n_rows, 0);
+    slot_of.resize(e1 - e0);
+    for (size_t i = e0; i < e1; ++i) { const int r = el[i].row; slot_of[i - e0] = (uint32_t)(start[(size_t)r] + cnt[(size_t)r]++); }
+    // phase A words: the elements in column order, then the fillers (value 0, the block's first column), in slices of
+    // 1024 words whose columns lie within 65536 of the slice's base
+    struct W { int32_t col; uint32_t slot; float val; };
+    std::vector<W> ws;
+    ws.reserve((e1 - e0) + (size_t)fillers);
+    for (size_t i = e0; i < e1; ++i) ws.push_back(W{el[i].col, slot_of[i - e0], el[i].val});
+    const int32_t first_col = e1 > e0 ? el[e0].col : 0;
+    {
+        // (cnt[] now holds each row's element count again)
+        std::vector<W> fl;
+        for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0) fl.push_back(W{first_col, (uint32_t)start[(size_t)r], 0.0f});
+        // fillers first: they share the block's first column, the real elements follow in ascending column order
+        ws.insert(ws.begin(), fl.begin(), fl.end());
+    }
+    size_t i = 0;
+    while (i < ws.size()) {
+        const int32_t base = ws[i].col & ~31;                         // 128-byte aligned
+        size_t j = i;
+        while (j < ws.size() && j - i < (size_t)kTtsChunk && ws[j].col - base < 65536) ++j;
+        out.col_base.push_back(base);
+        const size_t w0 = out.words.size();
+        out.words.resize(w0 + (size_t)kTtsChunk * 8);
+        uint32_t* vals = (uint32_t*)(out.words.data() + w0);
+        uint32_t* meta = vals + kTtsChunk;
+        // Word order inside a slice: the kernel reads 4 consecutive words per lane and step (one dwordx4 of values, one
+        // of metas) and gathers with one instruction per word position k -- so that the 64 lanes of a gather read 64
+        // CONSECUTIVE elements of the column order, sorted element 256 j + 64 k + l sits at word 256 j + 4 l + k.
+        // (Phase A has no order of its own: every word carries its slot.)
+        for (size_t q = 0; q < (size_t)kTtsChunk; ++q) {
+            const size_t step = q / 256, k = (q % 256) / 64, l = q % 64, at = 256 * step + 4 * l + k;
+            if (i + q < j) {
+                std::memcpy(&vals[at], &ws[i + q].val, 4);
+                meta[at] = ((uint32_t)(ws[i + q].col - base) << 16) | ws[i + q].slot;
+            } else { vals[at] = 0; meta[at] = (uint32_t)kTtsDummySlot; ++out.pads; }
+        }
+        // diagnostic: distinct 128-byte lines per 64-lane gather
+        for (size_t s0 = i; s0 < j; s0 += 64) {
+            int last = -1, n_lines = 0;
+            for (size_t q = s0; q < std::min(j, s0 + 64); ++q) { const int ln = ws[q].col >> 5; if (ln != last) { ++n_lines; last = ln; } }
+            out.lines += n_lines; out.gathers++;
+        }
+        i = j;
+    }
+    b.n_slices = (int32_t)out.col_base.size() - b.slice_begin;
+    out.blocks.push_back(b);
+    out.fillers += fillers;
+    out.max_slots = std::max(out.max_slots, n_slots);
+}
+
+}  // namespace
+
+TtsStream build_tts(const Csr& m, int64_t target_tile_elems) {
+    TtsStream S;
+    S.rows = m.rows; S.cols = m.cols; S.nnz = m.nnz();
+    const int32_t R = m.rows;
+    // row tiles: about `target` elements each (every row counts at least one), at most kTtsMaxRows rows.  More rows per
+    // tile = more elements per cache line of x in a gather (the tile's elements per column); the target keeps >= ~256
+    // tiles on large matrices so that every CU has one.
+    const int64_t total = S.nnz + R;
+    int64_t target = target_tile_elems > 0 ? target_tile_elems : std::max<int64_t>(total / 256, 24 * kTtsChunk);
+    struct Range { int32_t r0, r1; };
+    std::vector<Range> ranges;
+    for (int32_t r = 0; r < R;) {
+        int32_t e = r;
+        int64_t acc = 0;
+        while (e < R && e - r < kTtsMaxRows) {
+            const int64_t len = std::max<int64_t>(m.row_ptr[(size_t)e + 1] - m.row_ptr[e], 1);
+            if (e > r && acc + len > target) break;
+            acc += len; ++e;
+        }
+        ranges.push_back(Range{r, e});
+        r = e;
+    }
+    const size_t nt = ranges.size();
+    std::vector<TileOut> outs(nt);
+#pragma omp parallel
+    {
+        std::vector<Elem> el;
+        std::vector<int32_t> cnt((size_t)kTtsMaxRows), start((size_t)kTtsMaxRows), seen((size_t)kTtsMaxRows);
+        std::vector<uint32_t> slot_of;
+#pragma omp for schedule(dynamic, 1)
+        for (long long t = 0; t < (long long)nt; ++t) {
+            const Range rg = ranges[(size_t)t];
+            const int n_rows = rg.r1 - rg.r0;
+            el.clear();
+            for (int32_t r = rg.r0; r < rg.r1; ++r)
+                for (int64_t k = m.row_ptr[r]; k < m.row_ptr[(size_t)r + 1]; ++k) el.push_back(Elem{m.col[(size_t)k], r - rg.r0, m.val[(size_t)k]});
+            std::stable_sort(el.begin(), el.end(), [](const Elem& a, const Elem& b) { return a.col < b.col; });   // rows stay ascending inside a column
+            // blocks: greedy over the column-sorted list -- a block closes when its elements plus one filler for every
+            // row it has not seen would exceed the slot budget
+            TileOut& out = outs[(size_t)t];
+            std::fill(seen.begin(), seen.begin() + n_rows, -1);
+            size_t b0 = 0;
+            int block_id = 0, distinct = 0;
+            for (size_t i = 0; i <= el.size(); ++i) {
+                bool close = i == el.size();
+                if (!close) {
+                    const int r = el[i].row;
+                    const int add_distinct = seen[(size_t)r] != block_id ? 1 : 0;
+                    if ((int64_t)(i - b0 + 1) + (n_rows - distinct - add_distinct) > kTtsMaxSlots) close = true;
+                }
+                if (close) {
+                    pack_block(el, b0, i, n_rows, out, cnt, start, slot_of);
+                    if (i == el.size()) break;
+                    b0 = i; ++block_id; distinct = 0;
+                }
+                const int r = el[i].row;
+                if (seen[(size_t)r] != block_id) { seen[(size_t)r] = block_id; ++distinct; }
+            }
+        }
+    }
+    // concatenate the tiles
+    int64_t n_slices = 0, n_chunks = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        TileOut& o = outs[t];
+        TtsTile tile{ranges[t].r0, ranges[t].r1 - ranges[t].r0, (int32_t)S.blocks.size(), (int32_t)o.blocks.size()};
+        for (TtsBlock b : o.blocks) { b.slice_begin += (int32_t)n_slices; b.chunk_begin += (int32_t)n_chunks; S.blocks.push_back(b); }
+        S.tiles.push_back(tile);
+        n_slices += (int64_t)o.col_base.size(); n_chunks += (int64_t)o.chunk_info.size() / 2;
+        if (n_slices > INT32_MAX / 2 || n_chunks > INT32_MAX / 2) throw std::length_error("TTS stream too large");
+        S.n_fillers += o.fillers; S.n_pad_words += o.pads;
+        S.max_rows = std::max(S.max_rows, tile.n_rows); S.max_slots = std::max(S.max_slots, o.max_slots);
+    }
+    S.words.resize((size_t)n_slices * kTtsChunk * 8);
+    S.col_base.reserve((size_t)n_slices); S.flags.reserve((size_t)n_chunks * 64); S.chunk_info.reserve((size_t)n_chunks * 2);
+    size_t woff = 0;
+    double lines = 0; int64_t gathers = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        TileOut& o = outs[t];
+        std::memcpy(S.words.data() + woff, o.words.data(), o.words.size());
+        woff += o.words.size();
+        S.col_base.insert(S.col_base.end(), o.col_base.begin(), o.col_base.end());
+        S.flags.insert(S.flags.end(), o.flags.begin(), o.flags.end());
+        S.chunk_info.insert(S.chunk_info.end(), o.chunk_info.begin(), o.chunk_info.end());
+        lines += o.lines; gathers += o.gathers;
+        o = TileOut{};
+    }
+    S.lines_per_gather = gathers ? lines / (double)gathers : 0.0;
+    return S;
+}
+
+}  // namespace hispmv

@@ -1,0 +1,73 @@
+// hispmv_tts.h -- the TRANSPOSED TILE STREAM: second device format, for matrices whose rows are short and whose columns
+// are scattered (soc-Pokec, circuit matrices with wide jittered bands), where the slice stream gathers x with one L2
+// request per element.
+//
+// Lineage: the reference tiles the matrix in two dimensions, keeps the row sums of a row tile in per-PE URAM
+// accumulators across its column tiles and streams {row, col, value} words in an order chosen by the packer
+// (tileAndPad spmv-helper.cpp:242-263, AccumBuffer base_functions.cpp:439-519, encode spmv-helper.h:45-60).  Here:
+//   * a ROW TILE (<= kTtsMaxRows consecutive rows) belongs to one workgroup; its row sums live in LDS for the whole tile;
+//   * the tile is cut into BLOCKS along the columns; a block holds <= kTtsMaxSlots element slots;
+//   * inside a block the elements are streamed SORTED BY COLUMN -- the 64 lanes of a gather read neighbouring columns of
+//     x, a few cache lines per wave instruction instead of 64 -- as words {fp32 value, column offset:16 | slot:16};
+//     `slot` is the element's position in the block's ROW-MAJOR order;
+//   * phase A (column order): gather, multiply, ds_write the product to staging[slot] in LDS -- the transposition;
+//     phase B (row order): read the products back in row-major order and reduce them with the slice kernel's lane-local
+//     combine + DPP segmented scan, row ends from a bit per slot; row totals are added to the tile's LDS accumulators by
+//     the lane that owns the row end (plain read-modify-write: rows are distinct inside a wave, cut rows are finished
+//     from a carry slot after a barrier).  No atomics: ds_add_f32 takes 193 cycles per wave instruction on gfx950
+//     (tools/lds_atomic_bench.hip), a compare-and-swap loop collapses under contention.  Results are deterministic.
+//   * every row of the tile owns >= 1 slot in every block (zero-valued filler), so rows need no index list.
+// Host-only code (packer); the kernel is in hispmv_kernels.hip.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "hispmv_prep.h"
+
+namespace hispmv {
+
+constexpr int kTtsChunk = 1024;          // slots per row-major chunk / words per column-order slice
+constexpr int kTtsMaxSlots = 28 * 1024;  // slots of a block (112 KiB of staging)
+constexpr int kTtsMaxRows = 8 * 1024;    // rows of a tile (32 KiB of accumulators)
+constexpr int kTtsThreads = 1024;        // one 16-wave workgroup per CU (two 8-wave workgroups with half the LDS each: measured slower,
+                                         //   the tiles get shorter and every gather touches more lines of x)
+constexpr int kTtsDummySlot = kTtsMaxSlots;   // where padding words of phase A write
+
+struct TtsTile {           // 16 B per workgroup
+    int32_t row0;          // first row
+    int32_t n_rows;
+    int32_t block_begin;   // first block of the tile
+    int32_t n_blocks;
+};
+struct TtsBlock {          // 32 B
+    int32_t slice_begin;   // first column-order slice (1024 words each: values at words + slice*8192, metas 4096 B behind)
+    int32_t n_slices;
+    int32_t chunk_begin;   // first row-major chunk (flags: 64 x u16 per chunk; chunk table: {row_base, chain_len})
+    int32_t n_chunks;
+    int32_t n_slots;       // real slots (elements + fillers); the rest of the last chunk is padding without row ends
+    int32_t pad0, pad1, pad2;
+};
+
+struct TtsStream {
+    int32_t rows = 0, cols = 0;
+    int64_t nnz = 0;
+    std::vector<TtsTile> tiles;
+    std::vector<TtsBlock> blocks;
+    std::vector<uint8_t> words;          // per slice: 1024 x fp32 value, then 1024 x u32 meta (col_off << 16 | slot)
+    std::vector<int32_t> col_base;       // per slice: column the 16-bit offsets are relative to
+    std::vector<uint16_t> flags;         // per chunk: 64 x u16, bit 4j+k of lane l = row end at slot 256j + 4l + k
+    std::vector<int32_t> chunk_info;     // per chunk: {rows ending before the chunk (tile-local), chain_len: the first row
+                                         //   ending in the chunk began this many chunks earlier}
+    int64_t n_fillers = 0, n_pad_words = 0;
+    double lines_per_gather = 0;         // distinct 128-byte lines of x per 64-lane gather (diagnostic / format choice)
+    int max_rows = 0, max_slots = 0;
+    int64_t bytes() const {
+        return (int64_t)words.size() + (int64_t)col_base.size() * 4 + (int64_t)flags.size() * 2 + (int64_t)chunk_info.size() * 4 +
+               (int64_t)tiles.size() * 16 + (int64_t)blocks.size() * 32;
+    }
+};
+
+// Packs a CSR matrix (columns ascending per row).  `target_tile_elems`: elements per row tile (0 = chosen from the matrix).
+TtsStream build_tts(const Csr& m, int64_t target_tile_elems = 0);
+
+}  // namespace hispmv

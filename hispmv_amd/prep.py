@@ -31,9 +31,30 @@ class Prepared:
     staged_words: np.ndarray = None   # the stream as the device gets it: staged groups carry window indices, not columns
     groups: np.ndarray = None         # int32 [n_groups,4]: frag_begin, frag_count, lds_floats, 0
     frags: np.ndarray = None          # int32 [n_frags,4]: col_start, len, lds_off, 0
+    tts: dict = None                  # the transposed tile stream (prep_from_coo(..., tts=True)): arrays + counts
 
 
-def _collect(p) -> Prepared:
+def _collect_tts(p, target: int) -> dict:
+    cnt = (C.c_int64 * 8)()
+    lpg = C.c_double()
+    if lib.hispmv_prep_build_tts(p, int(target), cnt, C.byref(lpg)) != HISPMV_OK:
+        raise ValueError(lib.hispmv_prep_last_error().decode())
+    tiles, blocks, slices, chunks, fillers, pads, max_rows, max_slots = (int(v) for v in cnt)
+
+    def arr(which, n, dt, shape=None):
+        ptr = lib.hispmv_prep_tts_array(p, which)
+        if n == 0 or not ptr:
+            a = np.zeros(0, dtype=dt)
+        else:
+            a = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+        return a.reshape(shape) if shape else a
+    return dict(n_tiles=tiles, n_blocks=blocks, n_slices=slices, n_chunks=chunks, fillers=fillers, pad_words=pads, max_rows=max_rows,
+                max_slots=max_slots, lines_per_gather=float(lpg.value),
+                words=arr(0, slices * 2048, np.uint32, (-1, 2, 1024)), col_base=arr(1, slices, np.int32), flags=arr(2, chunks * 64, np.uint16, (-1, 64)),
+                chunk_info=arr(3, chunks * 2, np.int32, (-1, 2)), tiles=arr(4, tiles * 4, np.int32, (-1, 4)), blocks=arr(5, blocks * 8, np.int32, (-1, 8)))
+
+
+def _collect(p, tts=None) -> Prepared:
     d = (C.c_int64 * 8)()
     lib.hispmv_prep_dims(p, d)
     rows, cols, nnz, n_elems, n_slices, se, n_fix, nbytes = (int(v) for v in d)
@@ -59,11 +80,14 @@ def _collect(p) -> Prepared:
         out.staged_words = arr(lib.hispmv_prep_words(p), n_slices * se)
         out.groups = arr(lib.hispmv_prep_groups(p), int(cnt[0]) * 4, (-1, 4))
         out.frags = arr(lib.hispmv_prep_frags(p), int(cnt[1]) * 4, (-1, 4))
+    if tts is not None:
+        out.tts = _collect_tts(p, tts)
     lib.hispmv_prep_free(p)
     return out
 
 
-def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int) -> Prepared:
+def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int, tts=None) -> Prepared:
+    """tts: None, or the target elements per row tile of the transposed tile stream to pack as well (0 = loader's choice)."""
     r = np.ascontiguousarray(coo_rows, dtype=np.int32)
     c = np.ascontiguousarray(coo_cols, dtype=np.int32)
     v = np.ascontiguousarray(coo_values, dtype=np.float32)
@@ -72,7 +96,7 @@ def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int) -> Prepa
                                   C.c_void_p(v.ctypes.data), r.size, rows, cols)
     if rc != HISPMV_OK:
         raise ValueError(lib.hispmv_prep_last_error().decode())
-    return _collect(p)
+    return _collect(p, tts)
 
 
 def prep_from_coo_device(coo_rows, coo_cols, coo_values, rows: int, cols: int, device: int = 0):

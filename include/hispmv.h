@@ -156,6 +156,10 @@ typedef struct hispmv_matrix_info {
                                elements; the first tile also takes every column below, the last every column above */
     int32_t compact_slices; /* slices stored with 6-byte elements (fp32 value + 16-bit {rowEnd, index into the LDS window of x}); the
                                others take 8 bytes per element (32-bit meta) */
+    int32_t format;         /* 0 = slice stream (rows in order, segmented scan); 1 = transposed tile stream (scattered short-row matrices:
+                               row tiles with LDS accumulators, elements streamed sorted by column, transposed through LDS; n_slices then
+                               counts its 1024-word slices, n_split_rows is 0) */
+    float tts_lines_per_gather;  /* format 1: distinct 128-byte lines of x per 64-lane gather (64 = no lane shares a line) */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);
@@ -201,6 +205,15 @@ const int32_t* hispmv_prep_frags(const hispmv_prep* p);
 /* Number of device / pinned-memory frees the runtime rejected since the library was loaded (a pointer released twice
  * or never allocated); 0 in a correct run.  For tests. */
 int64_t hispmv_free_failures(void);
+
+/* The transposed tile stream of the prepared matrix (the second device format: hispmv_matrix_info.format == 1), packed
+ * on the host: counts = {tiles, blocks, column-order slices of 1024 words, row-major chunks of 1024 slots, fillers,
+ * padding words, max rows of a tile, max slots of a block}; arrays: 0 words (per slice 1024 x fp32 then 1024 x
+ * {col_off:16 | slot:16}), 1 col_base (int32 per slice), 2 flags (64 x u16 per chunk), 3 chunk_info ({rows ending
+ * before, chain_len} per chunk), 4 tiles ({row0, n_rows, block_begin, n_blocks}), 5 blocks (8 x int32: slice_begin,
+ * n_slices, chunk_begin, n_chunks, n_slots, 0, 0, 0).  target_tile_elems 0 = the loader's choice. */
+int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int64_t counts[8], double* lines_per_gather);
+const void* hispmv_prep_tts_array(const hispmv_prep* p, int which);
 
 /* Library identification: "hispmv-amd <version> gfx950". */
 const char* hispmv_version(void);

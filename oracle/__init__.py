@@ -72,6 +72,7 @@ def _load():
     lib.refpack_emulate.argtypes = [_p, _p, _p, C.c_float, C.c_float, _p]
     lib.emu_spmv.argtypes = [_p, _p, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int32, C.c_int]
     lib.emu_gemv.argtypes = [_p, C.c_int32, C.c_int32, _p, _p, C.c_float, C.c_float, _p]
+    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, _p, C.c_float, C.c_float, _p]
     return lib
 
 
@@ -297,6 +298,16 @@ def emu_spmv(words, hdr, fix, x, bias, alpha, beta, rows, mode=0):
     xx, bb = _c(x, np.float32), _c(bias, np.float32)
     y = np.zeros(rows, dtype=np.float32)
     lib.emu_spmv(_ptr(words), _ptr(hdr), _ptr(fix), hdr.shape[0], fix.shape[0], _ptr(xx), _ptr(bb), alpha, beta, _ptr(y), rows, mode)
+    return y
+
+
+def emu_tts(tts: dict, x, bias, alpha, beta, rows):
+    """CPU model of the transposed-tile-stream kernel on the product's own packed arrays (hispmv_amd.prep: Prepared.tts)."""
+    w, cb, fl, ci = _c(tts["words"], np.uint32), _c(tts["col_base"], np.int32), _c(tts["flags"], np.uint16), _c(tts["chunk_info"], np.int32)
+    ti, bl = _c(tts["tiles"], np.int32), _c(tts["blocks"], np.int32)
+    xx, bb = _c(x, np.float32), _c(bias, np.float32)
+    y = np.zeros(rows, dtype=np.float32)
+    lib.emu_tts(_ptr(w), _ptr(cb), _ptr(fl), _ptr(ci), _ptr(ti), _ptr(bl), tts["n_tiles"], _ptr(xx), _ptr(bb), alpha, beta, _ptr(y))
     return y
 
 

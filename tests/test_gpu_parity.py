@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 HW = ("tests.xclbin", 0, 24, 1, 1, 2, 5, True, False, True)   # apps/general_test.py:10-19
 
 
+@pytest.fixture(autouse=True)
+def slice_stream_only(monkeypatch):
+    """This module checks the SLICE stream bit for bit against its wavefront model; matrices that would take the
+    transposed tile stream (scattered short rows) are covered by tests/test_gpu_tts.py and test_gpu_bench_set.py."""
+    monkeypatch.setenv("HISPMV_FORMAT", "slices")
+
+
 @pytest.fixture(scope="module")
 def pyhispmv_mod():
     import pyhispmv
