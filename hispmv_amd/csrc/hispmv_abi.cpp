@@ -664,7 +664,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             d.n_tiles = (int32_t)ts.tiles.size(); d.rows = m.rows; d.cols = m.cols;
             d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = kTtsThreads;
             d.staging_floats = kTtsMaxSlots + 64;                 // (the dummy slot of padding words sits behind the last real one)
-            if (((size_t)d.acc_floats + d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
+            if (((size_t)d.acc_floats + (size_t)d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             p.tts = TtsStream{};
         } else {

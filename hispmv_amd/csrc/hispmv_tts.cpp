@@ -69,18 +69,14 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
     ws.reserve((e1 - e0) + (size_t)fillers);
     for (size_t i = e0; i < e1; ++i) ws.push_back(W{el[i].col, slot_of[i - e0], el[i].val});
     const int32_t first_col = e1 > e0 ? el[e0].col : 0;
-    {
-        // (cnt[] now holds each row's element count again)
-        std::vector<W> fl;
-        for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0) fl.push_back(W{first_col, (uint32_t)start[(size_t)r], 0.0f});
-        // fillers first: they share the block's first column, the real elements follow in ascending column order
-        ws.insert(ws.begin(), fl.begin(), fl.end());
-    }
+    // (cnt[] now holds each row's element count again)  fillers follow the elements: column -1 = "the base of whatever
+    // slice it lands in" (offset 0: a valid column, the gather is a broadcast)
+    for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0) ws.push_back(W{-1, (uint32_t)start[(size_t)r], 0.0f});
     size_t i = 0;
     while (i < ws.size()) {
-        const int32_t base = ws[i].col & ~31;                         // 128-byte aligned
+        const int32_t base = (ws[i].col >= 0 ? ws[i].col : first_col) & ~31;          // 128-byte aligned
         size_t j = i;
-        while (j < ws.size() && j - i < (size_t)kTtsChunk && ws[j].col - base < 65536) ++j;
+        while (j < ws.size() && j - i < (size_t)kTtsChunk && (ws[j].col < 0 || ws[j].col - base < 65536)) ++j;
         out.col_base.push_back(base);
         const size_t w0 = out.words.size();
         out.words.resize(w0 + (size_t)kTtsChunk * 8);
@@ -94,18 +90,19 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
             const size_t step = q / 256, k = (q % 256) / 64, l = q % 64, at = 256 * step + 4 * l + k;
             if (i + q < j) {
                 std::memcpy(&vals[at], &ws[i + q].val, 4);
-                meta[at] = ((uint32_t)(ws[i + q].col - base) << 16) | ws[i + q].slot;
+                meta[at] = ((uint32_t)(ws[i + q].col >= 0 ? ws[i + q].col - base : 0) << 16) | ws[i + q].slot;
             } else { vals[at] = 0; meta[at] = (uint32_t)kTtsDummySlot; ++out.pads; }
         }
         // diagnostic: distinct 128-byte lines per 64-lane gather
         for (size_t s0 = i; s0 < j; s0 += 64) {
             int last = -1, n_lines = 0;
-            for (size_t q = s0; q < std::min(j, s0 + 64); ++q) { const int ln = ws[q].col >> 5; if (ln != last) { ++n_lines; last = ln; } }
+            for (size_t q = s0; q < std::min(j, s0 + 64); ++q) { const int ln = (ws[q].col >= 0 ? ws[q].col : base) >> 5; if (ln != last) { ++n_lines; last = ln; } }
             out.lines += n_lines; out.gathers++;
         }
         i = j;
     }
     b.n_slices = (int32_t)out.col_base.size() - b.slice_begin;
+    if (b.n_slices > kTtsMaxBlockSlices) throw std::logic_error("internal: TTS block exceeds its slice budget");
     out.blocks.push_back(b);
     out.fillers += fillers;
     out.max_slots = std::max(out.max_slots, n_slots);
@@ -156,18 +153,28 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems) {
             std::fill(seen.begin(), seen.begin() + n_rows, -1);
             size_t b0 = 0;
             int block_id = 0, distinct = 0;
+            int sl_count = 0, sl_fill = 0, sl_base = 0;        // slices the block's elements take so far; fill and base of the open one
             for (size_t i = 0; i <= el.size(); ++i) {
                 bool close = i == el.size();
+                int n_sl = sl_count, n_fill = sl_fill, n_base = sl_base;
                 if (!close) {
                     const int r = el[i].row;
                     const int add_distinct = seen[(size_t)r] != block_id ? 1 : 0;
-                    if ((int64_t)(i - b0 + 1) + (n_rows - distinct - add_distinct) > kTtsMaxSlots) close = true;
+                    // the element opens a new slice when the open one is full or its 16-bit column offset would overflow
+                    if (sl_count == 0 || sl_fill == kTtsChunk || el[i].col - sl_base >= 65536) { n_sl = sl_count + 1; n_fill = 1; n_base = el[i].col & ~31; }
+                    else n_fill = sl_fill + 1;
+                    const int64_t fillers = n_rows - distinct - add_distinct;
+                    const int64_t extra = fillers - (kTtsChunk - n_fill);                   // fillers beyond the open slice's room
+                    const int64_t total_slices = n_sl + (extra > 0 ? (extra + kTtsChunk - 1) / kTtsChunk : 0);
+                    if ((int64_t)(i - b0 + 1) + fillers > kTtsMaxSlots || total_slices > kTtsMaxBlockSlices) close = true;
                 }
                 if (close) {
                     pack_block(el, b0, i, n_rows, out, cnt, start, slot_of);
                     if (i == el.size()) break;
                     b0 = i; ++block_id; distinct = 0;
+                    n_sl = 1; n_fill = 1; n_base = el[i].col & ~31;
                 }
+                sl_count = n_sl; sl_fill = n_fill; sl_base = n_base;
                 const int r = el[i].row;
                 if (seen[(size_t)r] != block_id) { seen[(size_t)r] = block_id; ++distinct; }
             }

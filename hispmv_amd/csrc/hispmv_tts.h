@@ -31,6 +31,7 @@ constexpr int kTtsMaxSlots = 28 * 1024;  // slots of a block (112 KiB of staging
 constexpr int kTtsMaxRows = 8 * 1024;    // rows of a tile (32 KiB of accumulators)
 constexpr int kTtsThreads = 1024;        // one 16-wave workgroup per CU (two 8-wave workgroups with half the LDS each: measured slower,
                                          //   the tiles get shorter and every gather touches more lines of x)
+constexpr int kTtsMaxBlockSlices = 48;  // column-order slices of a block (the 16-bit column offsets can cut slices short)
 constexpr int kTtsDummySlot = kTtsMaxSlots;   // where padding words of phase A write
 
 struct TtsTile {           // 16 B per workgroup
