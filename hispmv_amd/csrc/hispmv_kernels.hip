@@ -329,6 +329,7 @@ __device__ __forceinline__ void slices_group(
         // the lane's first row end in step j, the lane's further ends follow it.
         int r0[kSliceSteps];
         unsigned ends = 0;     // bit 4j + k = element k of step j ends its row
+        unsigned step_has_end = 0;   // wave-uniform: bit j = some row ends in step j
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             int below = 0, total = 0;
@@ -341,6 +342,7 @@ __device__ __forceinline__ void slices_group(
             }
             r0[j] = row + below;
             row += total;
+            step_has_end |= (total != 0 ? 1u : 0u) << j;
         }
 
         // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather)
@@ -395,14 +397,28 @@ __device__ __forceinline__ void slices_group(
         }
 
         // PreAccumulator + row distribution network: lane-local combine + segmented scan per 256-element step
-        float t[kE];
+        // A step in which no row ends (long rows: mouse_gene 642 per row, TSOPF 424) needs no scan: its 256 products join
+        // the open partial sum through a plain wave reduction with the scan's own tree (lane 63 of the scan is exactly
+        // that sum, so the bits do not change) -- a third of the scan's instructions; the slice kernel is VALU-bound on
+        // gfx950 once the stream is compact (PFlow_742: 72 % VALU busy at 5.9 TB/s).  The row totals of the other steps go
+        // to this wavefront's LDS tile right away (AccumBuffer), one ds_write per row end.
         float carry_step = 0.0f;       // partial sum of the row left open by the previous step
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            const float pj[kLaneElems] = {p[4 * j], p[4 * j + 1], p[4 * j + 2], p[4 * j + 3]};
-            float tj[kLaneElems];
-            scan_step(pj, (ends >> (4 * j)) & 0xfu, carry_step, tj);
-            t[4 * j] = tj[0]; t[4 * j + 1] = tj[1]; t[4 * j + 2] = tj[2]; t[4 * j + 3] = tj[3];
+            if (step_has_end & (1u << j)) {
+                const float pj[kLaneElems] = {p[4 * j], p[4 * j + 1], p[4 * j + 2], p[4 * j + 3]};
+                float tj[kLaneElems];
+                const unsigned e = (ends >> (4 * j)) & 0xfu;
+                scan_step(pj, e, carry_step, tj);
+                int pos = r0[j] - row_first;
+#pragma unroll
+                for (int k = 0; k < kLaneElems; ++k) {
+                    if (e & (1u << k)) ytile[pos] = tj[k];
+                    pos += (e >> k) & 1u;
+                }
+            } else {
+                carry_step = wave_sum(((p[4 * j] + p[4 * j + 1]) + p[4 * j + 2]) + p[4 * j + 3]) + carry_step;
+            }
         }
 
         bool deferred = false, rolling = false;
@@ -434,19 +450,9 @@ __device__ __forceinline__ void slices_group(
             if (rolling) { pend_slice = cur; pend_row = row_first; pend_len = chain_len; }
         }
 
-        // AccumBuffer -> Compute_C: the row totals go through this wavefront's LDS tile (one ds_write per row
-        // end) and leave as COALESCED y = alpha*total + beta*bias stores: ceil(n_rows/64) load/store pairs per
-        // slice instead of mostly-empty predicated ones (the output phase cost 25-30 % that way).
-#pragma unroll
-        for (int j = 0; j < kSliceSteps; ++j) {
-            const unsigned e = (ends >> (4 * j)) & 0xfu;
-            int pos = r0[j] - row_first;
-#pragma unroll
-            for (int k = 0; k < kLaneElems; ++k) {
-                if (e & (1u << k)) ytile[pos] = t[4 * j + k];
-                pos += (e >> k) & 1u;
-            }
-        }
+        // Compute_C: the row totals leave this wavefront's LDS tile as COALESCED y = alpha*total + beta*bias stores:
+        // ceil(n_rows/64) load/store pairs per slice instead of mostly-empty predicated ones (the output phase cost
+        // 25-30 % that way).
         const bool held = LOOKBACK && (deferred || rolling);   // the slice's first row is stored later, with its chain
         for (int i = lane; i < n_rows; i += 64) {
             const float tt = ytile[i];

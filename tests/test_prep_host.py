@@ -282,3 +282,38 @@ def _check_window_inversion(P):
         k = np.searchsorted(fr[:, 2], idx_in, side="right") - 1             # fragment holding each window index
         back = np.where(outside, idx & 0x3FFFFFFF, fr[k, 0] + (idx_in - fr[k, 2]))
         assert np.array_equal(back, gen_col[sl].reshape(-1))
+
+
+@pytest.mark.parametrize("shape", [(50000, 60000, 800000, 0), (3000, 200000, 400000, 0), (700, 900, 20000, 5000), (20000, 20000, 0, 0),
+                                   (40, 3000000, 12000, 0), (2, 100000, 700000, 0)])
+def test_transposed_tile_stream_packer_and_its_model(shape):
+    """The second device format (hispmv_tts.h), packed on the host and run through the CPU model of its kernel
+    (oracle.emu_tts): every row of a tile owns a slot in every block, slots are a permutation of the block's row-major
+    order, blocks respect their slot and slice budgets, and the product matches the fp64 accumulation -- including a heavy
+    row that spans many blocks, an empty matrix (fillers only) and slices cut short by the 16-bit column offsets."""
+    import oracle
+    rows, cols, nnz, target = shape
+    rng = np.random.default_rng(rows + nnz)
+    r = rng.integers(0, rows, nnz); c = rng.integers(0, cols, nnz)
+    if nnz > 1000:
+        r[: nnz // 4] = 1
+    v = rng.random(nnz, dtype=np.float32) - np.float32(0.5)
+    P = prep_from_coo(r, c, v, rows, cols, tts=target)
+    T = P.tts
+    tiles, blocks = T["tiles"], T["blocks"]
+    assert tiles[:, 1].sum() == rows and tiles[0, 0] == 0 and np.all(tiles[1:, 0] == tiles[:-1, 0] + tiles[:-1, 1])
+    assert blocks[:, 4].max() <= 28 * 1024 and blocks[:, 1].max() <= 48 and np.all(blocks[:, 3] == (blocks[:, 4] + 1023) // 1024)
+    assert blocks[:, 4].sum() == nnz + T["fillers"]
+    for t in (0, len(tiles) - 1):                       # slots of a block: each real slot written exactly once
+        for b in range(tiles[t, 2], tiles[t, 2] + tiles[t, 3]):
+            sb, ns, cb, nc, nslots = blocks[b, :5]
+            slots = T["words"][sb:sb + ns, 1, :].reshape(-1) & 0xFFFF
+            real = slots[slots != 28 * 1024]
+            assert real.size == nslots and np.array_equal(np.sort(real), np.arange(nslots))
+            ends = sum(bin(int(w)).count("1") for w in T["flags"][cb:cb + nc].reshape(-1))
+            assert ends == tiles[t, 1]                  # one row end per row of the tile in every block
+    x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
+    b = rng.random(rows, dtype=np.float32)
+    y = oracle.emu_tts(T, x, b, ALPHA, BETA, rows)
+    y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, ALPHA, BETA)
+    assert bwd_err(y, y64, mag) < TOL
