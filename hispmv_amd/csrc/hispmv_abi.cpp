@@ -295,7 +295,11 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     // several of them onto each cache line of x (hispmv_tts.h).  Takes the place of the L2-sized column tiles below.
     if (whole.lds_floats == 0 && c->format_mode != 0 && nnz_all >= 64 * 1024) {
         TtsStream ts = build_tts(csr);
-        if (c->format_mode == 1 || ts.lines_per_gather <= 32.0) {
+        // (a tile is one workgroup's work and a row is never split between tiles: a row far longer than the mean tile --
+        // Zipf row lengths at soc-Pokec's shape: one tile of 1.6 M slots against a mean of 134 K -- would be the critical
+        // path; such matrices keep the slice stream, which cuts rows at slice boundaries)
+        const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
+        if (c->format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced)) {
             Matrix::Part& p = m->parts[0];
             p.is_tts = true;
             p.tts = std::move(ts);

@@ -191,6 +191,9 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems) {
         if (n_slices > INT32_MAX / 2 || n_chunks > INT32_MAX / 2) throw std::length_error("TTS stream too large");
         S.n_fillers += o.fillers; S.n_pad_words += o.pads;
         S.max_rows = std::max(S.max_rows, tile.n_rows); S.max_slots = std::max(S.max_slots, o.max_slots);
+        int64_t tile_slots = 0;
+        for (const TtsBlock& b : o.blocks) tile_slots += b.n_slots;
+        S.total_slots += tile_slots; S.max_tile_slots = std::max(S.max_tile_slots, tile_slots);
     }
     S.words.resize((size_t)n_slices * kTtsChunk * 8);
     S.col_base.reserve((size_t)n_slices); S.flags.reserve((size_t)n_chunks * 64); S.chunk_info.reserve((size_t)n_chunks * 2);

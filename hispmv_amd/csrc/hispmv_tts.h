@@ -62,6 +62,7 @@ struct TtsStream {
     int64_t n_fillers = 0, n_pad_words = 0;
     double lines_per_gather = 0;         // distinct 128-byte lines of x per 64-lane gather (diagnostic / format choice)
     int max_rows = 0, max_slots = 0;
+    int64_t total_slots = 0, max_tile_slots = 0;   // a tile is one workgroup's work: a tile far above the mean (one very long row) is the critical path
     int64_t bytes() const {
         return (int64_t)words.size() + (int64_t)col_base.size() * 4 + (int64_t)flags.size() * 2 + (int64_t)chunk_info.size() * 4 +
                (int64_t)tiles.size() * 16 + (int64_t)blocks.size() * 32;

@@ -184,7 +184,7 @@ def test_model_test_layers_full_size(batch):
                 if kind == "dense" or not h.matrix_info(idx)["carry_lookback"]:
                     assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
                 else:
-                    assert np.allclose(one, out[:rows], rtol=2e-6, atol=0)
+                    assert np.allclose(one, out[:rows], rtol=1e-5, atol=1e-5 * float(np.max(np.abs(one))))
     finally:
         h.close()
 

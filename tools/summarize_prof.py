@@ -39,6 +39,25 @@ if stats:
     out.append("")
 
 
+# Step span from the kernel trace: the independent main launches of a step run on two HIP streams (their durations
+# overlap, so the sum of the kernel averages exceeds the step time); a step ends with its merge launch.
+trace = first("trace/**/*kernel_trace.csv")
+if trace:
+    ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace)) if "hispmv::" in r["Kernel_Name"]))
+    spans, start, busy = [], None, 0
+    for s0, e0, name in ev:
+        if start is None:
+            start = s0
+        if "merge_multi" in name:
+            spans.append((e0 - start) / 1e3)
+            start = None
+    if spans:
+        tail = spans[len(spans) // 2:]          # the later steps (past warm-up)
+        out += [f"Step span in the trace (first launch of a step to the end of its merge launch, last {len(tail)} steps): "
+                f"{sum(tail) / len(tail):.1f} us on average (min {min(tail):.1f}); under the profiler the chip clocks lower than in an "
+                "un-profiled run (MI355X_MICROARCH.md, DVFS), bench.py's HIP-event time is the un-profiled figure.", ""]
+
+
 def pmc(kind, counter):
     f = first(f"{kind}/**/*counter_collection.csv")
     if not f:
