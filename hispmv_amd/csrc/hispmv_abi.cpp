@@ -293,7 +293,12 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     const int32_t used = cmax >= cmin ? cmax - (cmin & ~63) + 1 : 0;
     // Scattered columns (no window pays): the transposed tile stream, when sorting a row tile's elements by column brings
     // several of them onto each cache line of x (hispmv_tts.h).  Takes the place of the L2-sized column tiles below.
-    if (whole.lds_floats == 0 && c->format_mode != 0 && nnz_all >= 64 * 1024) {
+    // (from 1 M entries: a tile is a long latency chain -- column-order pass, barrier, row-order pass per block --, the
+    // smallest matrices of the benchmark set run faster as slice streams: three alternating rounds, step of the set with
+    // two launch streams, threshold 64 K: 342-345 us, 1 M: 342-346 us, 4 M: 352-355 us; matrices alone: trans5 16.7 vs 10.1 us)
+    int64_t tts_min = 1 << 20;
+    if (const char* env = std::getenv("HISPMV_TTS_MIN_NNZ")) tts_min = std::atoll(env);       // experiments
+    if (whole.lds_floats == 0 && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
         TtsStream ts = build_tts(csr);
         // (a tile is one workgroup's work and a row is never split between tiles: a row far longer than the mean tile --
         // Zipf row lengths at soc-Pokec's shape: one tile of 1.6 M slots against a mean of 134 K -- would be the critical

@@ -101,14 +101,19 @@ def test_tile_stream_matches_its_model_and_the_fp64_truth(case, monkeypatch):
 
 
 def test_format_choice_follows_the_gather_locality(monkeypatch):
-    """auto: scattered short rows take the tile stream when a gather touches <= 32 lines of x; a matrix whose groups fit an
-    LDS window, a tiny matrix and HISPMV_FORMAT=slices keep the slice stream."""
+    """auto: matrices of >= 1 M entries with scattered short rows take the tile stream when a gather touches <= 32 lines
+    of x; a matrix whose groups fit an LDS window, smaller matrices and HISPMV_FORMAT=slices keep the slice stream."""
     import pyhispmv
     rng = np.random.default_rng(3)
     monkeypatch.delenv("HISPMV_FORMAT", raising=False)
     h = pyhispmv.FpgaHandle(*HW)
-    rows, cols, r, c, v = make("banded_jitter", rng)
+    rows = cols = 750000                      # 4.5 M entries: auto considers the tile stream from 1 M
+    r = np.repeat(np.arange(rows, dtype=np.int32), 6)
+    c = ((r + rng.integers(-40000, 40000, r.size)) % cols).astype(np.int32)
+    v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
     i_band = h.create_sparse_handle(r, c, v, rows, cols)
+    rs, cs, r_s, c_s, v_s = make("banded_jitter", rng)      # the same structure below the size threshold
+    i_small = h.create_sparse_handle(r_s, c_s, v_s, rs, cs)
     r2 = np.repeat(np.arange(20000, dtype=np.int32), 200)
     c2 = ((r2.astype(np.int64) + np.tile(np.arange(200), 20000)) % 20000).astype(np.int32)
     i_win = h.create_sparse_handle(r2, c2, np.ones(r2.size, np.float32), 20000, 20000)
@@ -116,6 +121,7 @@ def test_format_choice_follows_the_gather_locality(monkeypatch):
     h.load_matrices()
     a, b_, t = h.matrix_info(i_band), h.matrix_info(i_win), h.matrix_info(i_tiny)
     assert a["format"] == 1 and 0 < a["tts_lines_per_gather"] <= 32
+    assert h.matrix_info(i_small)["format"] == 0
     assert b_["format"] == 0 and b_["lds_bytes"] > 0
     assert t["format"] == 0
     h.close()
