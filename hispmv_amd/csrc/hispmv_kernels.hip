@@ -269,8 +269,11 @@ __device__ __forceinline__ void slices_group(
     SliceRaw<COMPACT> w;
     int4 h = int4{0, 0, 0, 0};
     if (local < n_here) {
-        request_slice<COMPACT>(w, gbase + (size_t)local * slice_bytes, lane);
+        // (the header first: a component of it that an instantiation does not use is a dead register hipcc reuses at
+        // once -- a write-after-write hazard with the load in flight, and waiting for the YOUNGEST load waits for the
+        // whole prefetch: s_waitcnt vmcnt(0) right behind the request, seen in the compact loop)
         h = load_int4(hdr + first + local);
+        request_slice<COMPACT>(w, gbase + (size_t)local * slice_bytes, lane);
     }
 
     if (LOOKBACK) {
@@ -392,8 +395,8 @@ __device__ __forceinline__ void slices_group(
         k_slice += n_waves;
         local = k_slice < n_here ? (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : n_here;
         if (local < n_here) {
+            h = load_int4(hdr + first + local);       // header first: see the prologue
             request_slice<COMPACT>(w, gbase + (size_t)local * slice_bytes, lane);
-            h = load_int4(hdr + first + local);
         }
 
         // PreAccumulator + row distribution network: lane-local combine + segmented scan per 256-element step
@@ -642,8 +645,8 @@ __device__ __forceinline__ void batched_group(
     SliceRaw<COMPACT> w;
     int4 h = int4{0, 0, 0, 0};
     if (slice < last) {
-        request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
         h = load_int4(hdr + slice);
+        request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
     }
     bool in_lds = false;
     if (USE_LDS) {
@@ -735,8 +738,8 @@ __device__ __forceinline__ void batched_group(
                 // vector's gathers (vmcnt retires in issue order: waiting for the gathers must not wait for the prefetch)
                 slice += n_waves;
                 if (slice < last) {
-                    request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
                     h = load_int4(hdr + slice);
+                    request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
                 }
             }
             float t[kE];
