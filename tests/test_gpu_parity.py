@@ -397,6 +397,38 @@ def test_multi_matrix_launch_matches_each_matrix_alone(fpga):
                                                   [m0["db"].data_ptr(), m1["db"].data_ptr()], [m0["dy"].data_ptr()] * 2), 1.0, 1.0)
 
 
+def test_csr_with_unsorted_rows_and_null_arrays(fpga):
+    """hispmv_create_sparse_handle_from_csr: rows whose columns are not ascending (scipy: has_sorted_indices == False) are
+    sorted on the way in -- same bits as the sorted matrix --, NULL column / value arrays with entries are rejected
+    (everything downstream takes a row's first and last column from its ends)."""
+    import ctypes as C
+    from hispmv_amd._lib import lib
+    rng = np.random.default_rng(21)
+    rows, cols, nnz = 3000, 2500, 90000
+    r = np.sort(rng.integers(0, rows, nnz)).astype(np.int32)
+    c = rng.integers(0, cols, nnz).astype(np.int32)                 # unsorted inside the rows
+    v = rng.random(nnz, dtype=np.float32) - np.float32(0.5)
+    rp = np.zeros(rows + 1, np.int64)
+    np.add.at(rp, r.astype(np.int64) + 1, 1)
+    rp = np.cumsum(rp).astype(np.int32)
+    order = np.lexsort((c, r))                                      # stable inside equal (row, col)
+    i_uns = fpga.create_sparse_handle_from_csr(rp, c, v, rows, cols)
+    i_srt = fpga.create_sparse_handle_from_csr(rp, c[order], v[order], rows, cols)
+    fpga.load_matrices()
+    x, b = rng.random(cols, dtype=np.float32), rng.random(rows, dtype=np.float32)
+    ys = []
+    for i in (i_uns, i_srt):
+        y = np.zeros(rows, np.float32)
+        fpga.select_matrix(i)
+        fpga.run_kernel(x, b, y, ALPHA, BETA)
+        ys.append(y)
+    assert np.array_equal(ys[0].view(np.uint32), ys[1].view(np.uint32))
+    y64, mag = oracle.spmv_f64(rp, c[order], v[order], x, b, ALPHA, BETA)
+    assert bwd_err(ys[0], y64, mag) < TOL
+    rc = lib.hispmv_create_sparse_handle_from_csr(fpga._ctx, C.c_void_p(rp.ctypes.data), None, None, rows, cols)
+    assert rc == -2                                                  # HISPMV_EINVAL
+
+
 def test_batch_tables_survive_the_first_host_vector_call(pyhispmv_mod):
     """Regression (round 1, hispmv_abi.cpp run_host_vectors): the first staged run_kernel / linear of a context grew the
     pinned staging block and, through a stray line, freed the device tables of earlier hispmv_spmv_device_batch calls

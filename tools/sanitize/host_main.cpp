@@ -1,10 +1,12 @@
 // Sanitizer driver for the host side (tools/sanitize_host.sh): random matrices of five kinds through
-// coo_to_csr -> build_stream -> make_plan, and the MatrixMarket reader on the files given as arguments.
+// coo_to_csr -> build_stream -> make_plan -> device layout, the transposed tile stream, unsorted CSR rows, and the
+// MatrixMarket reader on the files given as arguments.
 #include <cstdio>
 #include <random>
 
 #include "hispmv_plan.h"
 #include "hispmv_prep.h"
+#include "hispmv_tts.h"
 using namespace hispmv;
 
 int main(int argc, char** argv) {
@@ -29,7 +31,19 @@ int main(int argc, char** argv) {
         }
         Csr m = coo_to_csr(rows, cols, nnz, r.data(), c.data(), v.data());
         SliceStream st = build_stream(m);
-        for (int cus : {256, 8, 1}) { SliceStream copy = st; LaunchPlan p = make_plan(copy, cus); (void)p; }
+        for (int cus : {256, 8, 1}) { SliceStream copy = st; LaunchPlan p = make_plan(copy, cus); DeviceStream d = pack_device_stream(copy, p); (void)d; }
+        TtsStream ts = build_tts(m, t % 3 == 0 ? 5000 : 0);                      // the second device format
+        (void)ts;
+        if (t % 7 == 0) {                                                        // CSR handed over with unsorted rows
+            Csr u = m;
+            for (int32_t i = 0; i + 1 <= u.rows; ++i) {
+                const int64_t s0 = u.row_ptr[i], e0 = u.row_ptr[(size_t)i + 1];
+                if (e0 - s0 > 1) { std::swap(u.col[(size_t)s0], u.col[(size_t)e0 - 1]); std::swap(u.val[(size_t)s0], u.val[(size_t)e0 - 1]); }
+            }
+            sort_rows_by_column(u);
+            SliceStream su = build_stream(u);
+            (void)su;
+        }
     }
     {   // a stencil matrix large enough for LDS-window plans
         const int rows = 300000, per = 40;
