@@ -298,13 +298,24 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     // two launch streams, threshold 64 K: 342-345 us, 1 M: 342-346 us, 4 M: 352-355 us; matrices alone: trans5 16.7 vs 10.1 us)
     int64_t tts_min = 1 << 20;
     if (const char* env = std::getenv("HISPMV_TTS_MIN_NNZ")) tts_min = std::atoll(env);       // experiments
-    if (whole.lds_floats == 0 && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
+    // Candidates: plans without a window, and plans whose window leaves more than 5 % of the gathers to L2 (a wide band
+    // without column reuse between rows: the pessimistic stand-ins of PFlow_742 / Si41Ge41H72, 86 and 69 us with a 128 KiB
+    // window of the most used blocks) -- there the two formats are compared by their L2 requests per element.
+    const int64_t all_elems = m->parts[0].st.n_slices * (int64_t)kSliceElems;
+    const double slice_requests = whole.lds_floats == 0 ? 1.0
+                                 : ((double)whole.global_elems + (double)whole.staged_floats / kFragBlock) / (double)std::max<int64_t>(all_elems, 1);
+    // (x at most two windows wide is cut into two column tiles that each run from LDS: mouse_gene 56 us that way, 77 us as
+    // a tile stream)
+    const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096;
+    const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
+    if (candidate && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
         TtsStream ts = build_tts(csr);
         // (a tile is one workgroup's work and a row is never split between tiles: a row far longer than the mean tile --
         // Zipf row lengths at soc-Pokec's shape: one tile of 1.6 M slots against a mean of 134 K -- would be the critical
         // path; such matrices keep the slice stream, which cuts rows at slice boundaries)
         const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
-        if (c->format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced)) {
+        const bool fewer_requests = ts.lines_per_gather / 64.0 + 0.1 < slice_requests;     // (+0.1: the two passes and barriers of a block)
+        if (c->format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced && fewer_requests)) {
             Matrix::Part& p = m->parts[0];
             p.is_tts = true;
             p.tts = std::move(ts);
