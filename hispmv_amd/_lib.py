@@ -44,7 +44,7 @@ _f32p = C.POINTER(C.c_float)
 
 # name -> (restype, argtypes); every symbol include/hispmv.h declares.
 SIGNATURES = {
-    "hispmv_prep_build_tts": (C.c_int, [_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "hispmv_prep_build_tts": (C.c_int, [_p, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "hispmv_prep_tts_array": (C.c_void_p, [_p, C.c_int]),
     "hispmv_version": (C.c_char_p, []),
     "hispmv_free_failures": (C.c_int64, []),

@@ -310,6 +310,13 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
     if (candidate && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
         TtsStream ts = build_tts(csr);
+        if (ts.lines_per_gather <= 8.0 && std::getenv("HISPMV_TTS_SMALL")) {
+            // experiment (off by default: measured slower): cheap gathers -> the half-LDS geometry, two workgroups per CU
+            TtsGeometry small;
+            small.max_slots = kTtsSmallSlots; small.max_rows = kTtsSmallRows; small.tiles_wanted = 512;
+            TtsStream t2 = build_tts(csr, 0, small);
+            if (t2.lines_per_gather <= 16.0) ts = std::move(t2);
+        }
         // (a tile is one workgroup's work and a row is never split between tiles: a row far longer than the mean tile --
         // Zipf row lengths at soc-Pokec's shape: one tile of 1.6 M slots against a mean of 134 K -- would be the critical
         // path; such matrices keep the slice stream, which cuts rows at slice boundaries)
@@ -323,7 +330,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             m->format = 1; m->tts_lines_per_gather = p.tts.lines_per_gather;
             m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = 0;
             m->device_bytes = p.tts.bytes();
-            m->plan_threads = kTtsThreads; m->plan_group = 0; m->plan_lds = 0;
+            m->plan_threads = kTtsThreads; m->plan_group = p.tts.geometry.max_slots / kTtsChunk; m->plan_lds = 0;
             m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             csr = Csr{};
             if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
@@ -683,7 +690,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             d.words = dw; d.col_base = dcb; d.flags = dfl; d.chunk_info = (const int2*)dci; d.tiles = (const int4*)dt; d.blocks = (const int4*)db;
             d.n_tiles = (int32_t)ts.tiles.size(); d.rows = m.rows; d.cols = m.cols;
             d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = kTtsThreads;
-            d.staging_floats = kTtsMaxSlots + 64;                 // (the dummy slot of padding words sits behind the last real one)
+            d.staging_floats = ts.geometry.max_slots + 64;        // (the dummy slot of padding words sits behind the last real one)
             if (((size_t)d.acc_floats + (size_t)d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             p.tts = TtsStream{};
@@ -869,26 +876,29 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         HIP_TRY(c, hipMemcpy(l.d_table, host, bytes, hipMemcpyHostToDevice));
         return HISPMV_OK;
     };
-    {   // transposed tile streams: their row tiles share one grid of 1024-thread workgroups
+    for (int geometry = 0; geometry < 2; ++geometry) {
+        // transposed tile streams: their row tiles share one grid of 1024-thread workgroups per geometry (the launch's
+        // LDS size is the largest of its entries: the half-LDS tiles must not ride with the tall ones)
         hispmv_ctx::BatchLaunch l;
         l.kind = 3;
+        auto flush = [&]() -> int {
+            if (l.tts.empty()) return HISPMV_OK;
+            plan.launches.push_back(std::move(l));
+            const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().tts.data(), plan.launches.back().tts.size() * sizeof(TtsEntry));
+            l = hispmv_ctx::BatchLaunch{};
+            l.kind = 3;
+            return rc0;
+        };
         for (int i = 0; i < n; ++i) {
             Matrix& m = *c->mats[idx[i]];
             if (m.dense || m.format != 1) continue;
+            const bool small = m.parts[0].tdev.staging_floats <= kTtsSmallSlots + 64;
+            if ((int)small != geometry) continue;
             l.tts.push_back(TtsEntry{m.parts[0].tdev, d_x[i], bias[i], d_y[i], beta, 0});
-            if ((int)l.tts.size() == kMultiMax) {
-                plan.launches.push_back(std::move(l));
-                const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().tts.data(), plan.launches.back().tts.size() * sizeof(TtsEntry));
-                if (rc0 != HISPMV_OK) return rc0;
-                l = hispmv_ctx::BatchLaunch{};
-                l.kind = 3;
-            }
+            if ((int)l.tts.size() == kMultiMax) { const int rc0 = flush(); if (rc0 != HISPMV_OK) return rc0; }
         }
-        if (!l.tts.empty()) {
-            plan.launches.push_back(std::move(l));
-            const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().tts.data(), plan.launches.back().tts.size() * sizeof(TtsEntry));
-            if (rc0 != HISPMV_OK) return rc0;
-        }
+        const int rc0 = flush();
+        if (rc0 != HISPMV_OK) return rc0;
     }
     for (int i = 0; i < n; ++i) {
         const Matrix& m = *c->mats[idx[i]];
@@ -1178,10 +1188,12 @@ HISPMV_API int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[
 HISPMV_API const int32_t* hispmv_prep_groups(const hispmv_prep* p) { return (const int32_t*)p->plan.groups.data(); }
 HISPMV_API const int32_t* hispmv_prep_frags(const hispmv_prep* p) { return (const int32_t*)p->plan.frags.data(); }
 
-HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int64_t counts[8], double* lines_per_gather) {
+HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int small_geometry, int64_t counts[8], double* lines_per_gather) {
     if (!p || !counts) return HISPMV_EINVAL;
     try {
-        p->tts = build_tts(p->csr, target_tile_elems);
+        TtsGeometry geo;
+        if (small_geometry) { geo.max_slots = kTtsSmallSlots; geo.max_rows = kTtsSmallRows; geo.tiles_wanted = 512; }
+        p->tts = build_tts(p->csr, target_tile_elems, geo);
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
     const TtsStream& t = p->tts;
     counts[0] = (int64_t)t.tiles.size(); counts[1] = (int64_t)t.blocks.size(); counts[2] = (int64_t)t.col_base.size();

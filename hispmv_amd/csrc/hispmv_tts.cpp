@@ -24,7 +24,7 @@ struct Elem { int32_t col; int32_t row; float val; };     // row: tile-local
 
 // One block: elements [e0, e1) of the tile's column-sorted list.
 void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, TileOut& out, std::vector<int32_t>& cnt,
-                std::vector<int32_t>& start, std::vector<uint32_t>& slot_of) {
+                std::vector<int32_t>& start, std::vector<uint32_t>& slot_of, const TtsGeometry& geo) {
     // row-major order of the block: rows ascending, inside a row the elements in column order (the order of `el`), a row
     // without elements in this block gets one filler slot
     std::fill(cnt.begin(), cnt.begin() + n_rows, 0);
@@ -32,7 +32,7 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
     int32_t pos = 0, fillers = 0;
     for (int r = 0; r < n_rows; ++r) { start[(size_t)r] = pos; if (cnt[(size_t)r] == 0) { ++fillers; pos += 1; } else pos += cnt[(size_t)r]; }
     const int32_t n_slots = pos;
-    if (n_slots > kTtsMaxSlots) throw std::logic_error("internal: TTS block exceeds its slot budget");
+    if (n_slots > geo.max_slots) throw std::logic_error("internal: TTS block exceeds its slot budget");
     const int32_t n_chunks = (n_slots + kTtsChunk - 1) / kTtsChunk;
     TtsBlock b{};
     b.slice_begin = (int32_t)out.col_base.size();
@@ -91,7 +91,7 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
             if (i + q < j) {
                 std::memcpy(&vals[at], &ws[i + q].val, 4);
                 meta[at] = ((uint32_t)(ws[i + q].col >= 0 ? ws[i + q].col - base : 0) << 16) | ws[i + q].slot;
-            } else { vals[at] = 0; meta[at] = (uint32_t)kTtsDummySlot; ++out.pads; }
+            } else { vals[at] = 0; meta[at] = (uint32_t)geo.max_slots; ++out.pads; }
         }
         // diagnostic: distinct 128-byte lines per 64-lane gather
         for (size_t s0 = i; s0 < j; s0 += 64) {
@@ -110,21 +110,22 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
 
 }  // namespace
 
-TtsStream build_tts(const Csr& m, int64_t target_tile_elems) {
+TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     TtsStream S;
+    S.geometry = geo;
     S.rows = m.rows; S.cols = m.cols; S.nnz = m.nnz();
     const int32_t R = m.rows;
     // row tiles: about `target` elements each (every row counts at least one), at most kTtsMaxRows rows.  More rows per
     // tile = more elements per cache line of x in a gather (the tile's elements per column); the target keeps >= ~256
     // tiles on large matrices so that every CU has one.
     const int64_t total = S.nnz + R;
-    int64_t target = target_tile_elems > 0 ? target_tile_elems : std::max<int64_t>(total / 256, 24 * kTtsChunk);
+    int64_t target = target_tile_elems > 0 ? target_tile_elems : std::max<int64_t>(total / geo.tiles_wanted, std::min(24 * kTtsChunk, geo.max_slots));
     struct Range { int32_t r0, r1; };
     std::vector<Range> ranges;
     for (int32_t r = 0; r < R;) {
         int32_t e = r;
         int64_t acc = 0;
-        while (e < R && e - r < kTtsMaxRows) {
+        while (e < R && e - r < geo.max_rows) {
             const int64_t len = std::max<int64_t>(m.row_ptr[(size_t)e + 1] - m.row_ptr[e], 1);
             if (e > r && acc + len > target) break;
             acc += len; ++e;
@@ -166,10 +167,10 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems) {
                     const int64_t fillers = n_rows - distinct - add_distinct;
                     const int64_t extra = fillers - (kTtsChunk - n_fill);                   // fillers beyond the open slice's room
                     const int64_t total_slices = n_sl + (extra > 0 ? (extra + kTtsChunk - 1) / kTtsChunk : 0);
-                    if ((int64_t)(i - b0 + 1) + fillers > kTtsMaxSlots || total_slices > kTtsMaxBlockSlices) close = true;
+                    if ((int64_t)(i - b0 + 1) + fillers > geo.max_slots || total_slices > kTtsMaxBlockSlices) close = true;
                 }
                 if (close) {
-                    pack_block(el, b0, i, n_rows, out, cnt, start, slot_of);
+                    pack_block(el, b0, i, n_rows, out, cnt, start, slot_of, geo);
                     if (i == el.size()) break;
                     b0 = i; ++block_id; distinct = 0;
                     n_sl = 1; n_fill = 1; n_base = el[i].col & ~31;

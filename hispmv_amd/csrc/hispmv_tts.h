@@ -32,7 +32,13 @@ constexpr int kTtsMaxRows = 8 * 1024;    // rows of a tile (32 KiB of accumulato
 constexpr int kTtsThreads = 1024;        // one 16-wave workgroup per CU (two 8-wave workgroups with half the LDS each: measured slower,
                                          //   the tiles get shorter and every gather touches more lines of x)
 constexpr int kTtsMaxBlockSlices = 48;  // column-order slices of a block (the 16-bit column offsets can cut slices short)
-constexpr int kTtsDummySlot = kTtsMaxSlots;   // where padding words of phase A write
+// A second geometry (HISPMV_TTS_SMALL=1; not used by default): half the LDS per workgroup, so that TWO 16-wavefront
+// workgroups share a CU and one's column-order pass overlaps the other's row-order pass.  Tried for matrices whose
+// gathers are cheap anyway (<= 8 lines per gather with the tall tiles; the tall geometry spends half of its wave cycles
+// waiting there): PFlow_742 as an unstructured band 81.9 -> 93.4 us, Si41Ge41H72 39.5 -> 48.0 us, boyd2 18.7 -> 14.6 us.
+constexpr int kTtsSmallSlots = 13 * 1024;
+constexpr int kTtsSmallRows = 4 * 1024;
+struct TtsGeometry { int max_slots = kTtsMaxSlots, max_rows = kTtsMaxRows, tiles_wanted = 256; };
 
 struct TtsTile {           // 16 B per workgroup
     int32_t row0;          // first row
@@ -62,6 +68,7 @@ struct TtsStream {
     int64_t n_fillers = 0, n_pad_words = 0;
     double lines_per_gather = 0;         // distinct 128-byte lines of x per 64-lane gather (diagnostic / format choice)
     int max_rows = 0, max_slots = 0;
+    TtsGeometry geometry;                // what it was packed for (padding words of phase A write to slot geometry.max_slots)
     int64_t total_slots = 0, max_tile_slots = 0;   // a tile is one workgroup's work: a tile far above the mean (one very long row) is the critical path
     int64_t bytes() const {
         return (int64_t)words.size() + (int64_t)col_base.size() * 4 + (int64_t)flags.size() * 2 + (int64_t)chunk_info.size() * 4 +
@@ -69,7 +76,8 @@ struct TtsStream {
     }
 };
 
-// Packs a CSR matrix (columns ascending per row).  `target_tile_elems`: elements per row tile (0 = chosen from the matrix).
-TtsStream build_tts(const Csr& m, int64_t target_tile_elems = 0);
+// Packs a CSR matrix (columns ascending per row).  `target_tile_elems`: elements per row tile (0 = chosen from the matrix
+// and the geometry).
+TtsStream build_tts(const Csr& m, int64_t target_tile_elems = 0, TtsGeometry geometry = TtsGeometry());
 
 }  // namespace hispmv

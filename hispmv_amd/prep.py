@@ -34,10 +34,12 @@ class Prepared:
     tts: dict = None                  # the transposed tile stream (prep_from_coo(..., tts=True)): arrays + counts
 
 
-def _collect_tts(p, target: int) -> dict:
+def _collect_tts(p, target, small: bool = False) -> dict:
+    if isinstance(target, tuple):
+        target, small = target
     cnt = (C.c_int64 * 8)()
     lpg = C.c_double()
-    if lib.hispmv_prep_build_tts(p, int(target), cnt, C.byref(lpg)) != HISPMV_OK:
+    if lib.hispmv_prep_build_tts(p, int(target), int(bool(small)), cnt, C.byref(lpg)) != HISPMV_OK:
         raise ValueError(lib.hispmv_prep_last_error().decode())
     tiles, blocks, slices, chunks, fillers, pads, max_rows, max_slots = (int(v) for v in cnt)
 
@@ -87,7 +89,8 @@ def _collect(p, tts=None) -> Prepared:
 
 
 def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int, tts=None) -> Prepared:
-    """tts: None, or the target elements per row tile of the transposed tile stream to pack as well (0 = loader's choice)."""
+    """tts: None, or the target elements per row tile of the transposed tile stream to pack as well (0 = loader's choice),
+    or (target, small_geometry) -- see hispmv_prep_build_tts."""
     r = np.ascontiguousarray(coo_rows, dtype=np.int32)
     c = np.ascontiguousarray(coo_cols, dtype=np.int32)
     v = np.ascontiguousarray(coo_values, dtype=np.float32)

@@ -147,7 +147,7 @@ typedef struct hispmv_matrix_info {
     int64_t device_bytes;   /* bytes this handle takes in the arena */
     double prep_seconds;    /* host preprocessing time ("Pre-processing Time") */
     int32_t block_threads;  /* launch plan chosen at load time: workgroup size, */
-    int32_t group_slices;   /*   slices per workgroup, */
+    int32_t group_slices;   /*   slices per workgroup (format 1: K-slots per block of the tile geometry, 28 or 13), */
     int32_t lds_bytes;      /*   LDS bytes of the x window (0 = x gathered through L2) */
     int32_t col_tiles;      /* number of column tiles (1 = untiled) */
     int32_t carry_lookback; /* 1 = rows shared between slices are merged inside the launch (look-back), 0 = fix-up launch */
@@ -211,8 +211,10 @@ int64_t hispmv_free_failures(void);
  * padding words, max rows of a tile, max slots of a block}; arrays: 0 words (per slice 1024 x fp32 then 1024 x
  * {col_off:16 | slot:16}), 1 col_base (int32 per slice), 2 flags (64 x u16 per chunk), 3 chunk_info ({rows ending
  * before, chain_len} per chunk), 4 tiles ({row0, n_rows, block_begin, n_blocks}), 5 blocks (8 x int32: slice_begin,
- * n_slices, chunk_begin, n_chunks, n_slots, 0, 0, 0).  target_tile_elems 0 = the loader's choice. */
-int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int64_t counts[8], double* lines_per_gather);
+ * n_slices, chunk_begin, n_chunks, n_slots, 0, 0, 0).  target_tile_elems 0 = the loader's choice; small_geometry: 0 = tiles of
+ * <= 8192 rows and blocks of <= 28 K slots (one workgroup per CU), 1 = <= 4096 rows / 13 K slots (two per CU: what the
+ * loader takes when a gather of the tall geometry touches <= 8 lines; hispmv_matrix_info.group_slices = 28 or 13). */
+int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int small_geometry, int64_t counts[8], double* lines_per_gather);
 const void* hispmv_prep_tts_array(const hispmv_prep* p, int which);
 
 /* Library identification: "hispmv-amd <version> gfx950". */
