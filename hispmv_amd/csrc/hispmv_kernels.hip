@@ -31,24 +31,38 @@ namespace hispmv {
 __device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
 __device__ __forceinline__ float i2f(int i) { return __builtin_bit_cast(float, i); }
 
-// One Kogge-Stone step of the segmented inclusive scan on (head flag F, value v):
+// Segmented inclusive scan over the 64 lanes, Kogge-Stone on (head flag F, value v):
 //   (F1,v1) o (F2,v2) = (F1|F2, F2 ? v2 : v1+v2)
 // CTRL/ROWMASK select the DPP source; lanes without a source read the identity (0,0).
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ void seg_scan_step(float& v, int& F) {
-    const float vp = i2f(__builtin_amdgcn_update_dpp(0, f2i(v), CTRL, ROWMASK, 0xf, false));
-    const int Fp = __builtin_amdgcn_update_dpp(0, F, CTRL, ROWMASK, 0xf, false);
-    v = F ? v : v + vp;
-    F |= Fp;
+// The flags never depend on the values: the F of every stage is computed from the ballot of the head flags on the
+// SCALAR unit (shifts inside the 16-lane DPP rows, then the two row broadcasts) and handed to the select through
+// inverse_ballot -- per stage one v_add_f32_dpp and one v_cndmask instead of those plus a v_or_b32_dpp and a v_cmp
+// (the slice kernel is VALU-bound on gfx950: 88-119 VALU instructions per 256-element step before, 51-66 after).
+struct ScanFlags { unsigned long long f[7]; };    // F before stage 0..5, and after the last one
+__device__ __forceinline__ ScanFlags scan_flags(unsigned long long heads) {
+    ScanFlags s;
+    s.f[0] = heads;
+    s.f[1] = s.f[0] | ((s.f[0] << 1) & 0xfffefffefffefffeull);     // row_shr:1
+    s.f[2] = s.f[1] | ((s.f[1] << 2) & 0xfffcfffcfffcfffcull);     // row_shr:2
+    s.f[3] = s.f[2] | ((s.f[2] << 4) & 0xfff0fff0fff0fff0ull);     // row_shr:4
+    s.f[4] = s.f[3] | ((s.f[3] << 8) & 0xff00ff00ff00ff00ull);     // row_shr:8
+    s.f[5] = s.f[4] | (((s.f[4] >> 15) & 1ull) ? 0x00000000ffff0000ull : 0ull)     // row_bcast:15 -> rows 1,3
+                    | (((s.f[4] >> 47) & 1ull) ? 0xffff000000000000ull : 0ull);
+    s.f[6] = s.f[5] | (((s.f[5] >> 31) & 1ull) ? 0xffffffff00000000ull : 0ull);    // row_bcast:31 -> rows 2,3
+    return s;
 }
-
-__device__ __forceinline__ void seg_scan_wave(float& v, int& F) {
-    seg_scan_step<0x111, 0xf>(v, F);   // row_shr:1
-    seg_scan_step<0x112, 0xf>(v, F);   // row_shr:2
-    seg_scan_step<0x114, 0xf>(v, F);   // row_shr:4
-    seg_scan_step<0x118, 0xf>(v, F);   // row_shr:8
-    seg_scan_step<0x142, 0xa>(v, F);   // row_bcast:15 -> rows 1,3
-    seg_scan_step<0x143, 0xc>(v, F);   // row_bcast:31 -> rows 2,3
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void seg_scan_step(float& v, unsigned long long F) {
+    const float vp = i2f(__builtin_amdgcn_update_dpp(0, f2i(v), CTRL, ROWMASK, 0xf, false));
+    v = __builtin_amdgcn_inverse_ballot_w64(F) ? v : v + vp;
+}
+__device__ __forceinline__ void seg_scan_wave(float& v, const ScanFlags& s) {
+    seg_scan_step<0x111, 0xf>(v, s.f[0]);   // row_shr:1
+    seg_scan_step<0x112, 0xf>(v, s.f[1]);   // row_shr:2
+    seg_scan_step<0x114, 0xf>(v, s.f[2]);   // row_shr:4
+    seg_scan_step<0x118, 0xf>(v, s.f[3]);   // row_shr:8
+    seg_scan_step<0x142, 0xa>(v, s.f[4]);   // row_bcast:15 -> rows 1,3
+    seg_scan_step<0x143, 0xc>(v, s.f[5]);   // row_bcast:31 -> rows 2,3
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -202,17 +216,17 @@ __device__ __forceinline__ void decode_metas(const SliceRaw<COMPACT>& s, unsigne
 // right inside row segments, the open tails go through the DPP segmented scan, and every row end gets its total.
 //   p[k], e[k]: products and row-end flags of the lane's elements; carry_step: partial of the row left open by the
 //   previous step (in/out); t[k]: total of the row that ends at element k (meaningful where e[k]).
-__device__ __forceinline__ void scan_step(const float (&p)[kLaneElems], unsigned e, float& carry_step, float (&t)[kLaneElems]) {
-    const bool e0 = e & 1u, e1 = e & 2u, e2 = e & 4u, e3 = e & 8u;
+__device__ __forceinline__ void scan_step(const float (&p)[kLaneElems], bool e0, bool e1, bool e2, bool e3, float& carry_step,
+                                          float (&t)[kLaneElems]) {
     const float s0 = p[0];
     const float s1 = e0 ? p[1] : s0 + p[1];
     const float s2 = e1 ? p[2] : s1 + p[2];
     const float s3 = e2 ? p[3] : s2 + p[3];
     // what this lane hands to its right neighbour, and whether it cuts the chain
     float v = e3 ? 0.0f : s3;
-    int F = e ? 1 : 0;
+    const ScanFlags F = scan_flags(__builtin_amdgcn_ballot_w64(e0 | e1 | e2 | e3));
     seg_scan_wave(v, F);
-    v = F ? v : v + carry_step;
+    v = __builtin_amdgcn_inverse_ballot_w64(F.f[6]) ? v : v + carry_step;
     // incoming partial for this lane = inclusive value of the lane below (lane 0: previous step)
     const float cin = i2f(__builtin_amdgcn_update_dpp(f2i(carry_step), f2i(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
     carry_step = i2f(__builtin_amdgcn_readlane(f2i(v), 63));
@@ -240,6 +254,7 @@ __device__ __forceinline__ void slices_group(
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, cols * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, rows * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, rows * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)carry, 0, LOOKBACK ? 0 : (int)(n_slices * 4), 0x00020000);
     constexpr unsigned kNoAccess = 0xffffffffu;
     constexpr int kE = kSliceSteps * kLaneElems;     // elements of a slice per lane (16)
     const int lane = threadIdx.x & 63;
@@ -312,8 +327,22 @@ __device__ __forceinline__ void slices_group(
     long long def_slice = -1, pend_slice = -1;
     int def_row = 0, def_len = 0, pend_row = 0, pend_len = 0;
     float def_t = 0.0f, def_b = 0.0f, pend_t = 0.0f, pend_b = 0.0f;
+    // Fix-up variant: the stores of a slice (its first 128 rows of y and its carry) are held in registers and issued at
+    // the top of the wavefront's NEXT iteration, behind the wait for that iteration's slice.  gfx9 counts loads and
+    // stores on the same vmcnt and lets them retire out of order with each other, so with a store pending every wait
+    // for a load is vmcnt(0): issued at the end of the iteration, the stores made the wait for the prefetched slice a
+    // wait for their write acknowledgements as well.  (An offset of kNoAccess = no store.)
+    // With beta != 0 the bias values of those rows are consumed there too: nothing in the middle of an iteration waits on
+    // vmcnt, where the wait would also cover the prefetch issued a moment earlier.
+    float out_t0 = 0.0f, out_t1 = 0.0f, out_b0 = 0.0f, out_b1 = 0.0f, out_carry = 0.0f;
+    unsigned out_d0 = kNoAccess, out_d1 = kNoAccess, out_dc = kNoAccess;
 
     while (local < n_here) {
+        // (every component of the header stays live up to here: a component an instantiation does not use is a dead
+        // register hipcc hands out as a temporary while the load is in flight -- a write-after-write hazard it covers by
+        // waiting for the header, i.e. a full memory latency right behind the prefetch: "s_waitcnt vmcnt(8)" in the first
+        // scan block)
+        asm volatile("" :: "v"(h.x), "v"(h.y), "v"(h.z), "v"(h.w));
         int row = __builtin_amdgcn_readfirstlane(h.x);
         const int row_first = row;                                   // first row that ends in this slice
         const int chain_len = __builtin_amdgcn_readfirstlane(h.y);   // >0: that row began chain_len slices earlier
@@ -321,27 +350,33 @@ __device__ __forceinline__ void slices_group(
         const bool spills = USE_LDS && __builtin_amdgcn_readfirstlane(h.w) != 0;   // elements outside the x window (wide groups only)
         // Compute_C operand: the slice's rows are consecutive, so bias is read with coalesced loads that leave
         // together with the x gathers (first 128 rows here, the rest in the epilogue loop).
+        unsigned c[kE];
+        decode_metas<COMPACT>(w, c);
+        if (!LOOKBACK) {
+            asm volatile("" : "+v"(c[0]), "+v"(c[kE - 1]) :: "memory");      // behind the wait for this slice
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * out_t0 + beta * out_b0 : alpha * out_t0), ry, out_d0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * out_t1 + beta * out_b1 : alpha * out_t1), ry, out_d1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(out_carry), rc, out_dc, 0, 0);
+        }
         float bpre0 = 0.0f, bpre1 = 0.0f;
         if (HAS_BETA) {
             bpre0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane < n_rows ? (unsigned)(row_first + lane) << 2 : kNoAccess, 0, 0));
             bpre1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, lane + 64 < n_rows ? (unsigned)(row_first + lane + 64) << 2 : kNoAccess, 0, 0));
         }
-        unsigned c[kE];
-        decode_metas<COMPACT>(w, c);
         // Local row ids of every row end (ballots + mbcnt prefix counts; no per-element row field): r0[j] = row of
         // the lane's first row end in step j, the lane's further ends follow it.
         int r0[kSliceSteps];
-        unsigned ends = 0;     // bit 4j + k = element k of step j ends its row
+        bool ends[kE];         // element k of step j ends its row (kept as lane masks: no per-lane bit field to build and test)
         unsigned step_has_end = 0;   // wave-uniform: bit j = some row ends in step j
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             int below = 0, total = 0;
 #pragma unroll
             for (int k = 0; k < kLaneElems; ++k) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64((c[4 * j + k] & kRowEndBit) != 0);
+                ends[4 * j + k] = (c[4 * j + k] & kRowEndBit) != 0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ends[4 * j + k]);
                 below += lanes_below(m);
                 total += __builtin_popcountll(m);
-                ends |= (c[4 * j + k] >> 31) << (4 * j + k);
             }
             r0[j] = row + below;
             row += total;
@@ -350,7 +385,7 @@ __device__ __forceinline__ void slices_group(
 
         // LoadB / ComputeAB operands: x[col] (LDS window or L2 gather)
         float xv[kE];
-        if (USE_LDS && in_lds && !spills) {
+        if (COMPACT || (USE_LDS && in_lds && !spills)) {     // (a compact group has every element in its window)
 #pragma unroll
             for (int i = 0; i < kE; ++i) xv[i] = xs[c[i] & ~kRowEndBit];
         } else if (USE_LDS && in_lds) {
@@ -411,13 +446,12 @@ __device__ __forceinline__ void slices_group(
             if (step_has_end & (1u << j)) {
                 const float pj[kLaneElems] = {p[4 * j], p[4 * j + 1], p[4 * j + 2], p[4 * j + 3]};
                 float tj[kLaneElems];
-                const unsigned e = (ends >> (4 * j)) & 0xfu;
-                scan_step(pj, e, carry_step, tj);
+                scan_step(pj, ends[4 * j], ends[4 * j + 1], ends[4 * j + 2], ends[4 * j + 3], carry_step, tj);
                 int pos = r0[j] - row_first;
 #pragma unroll
                 for (int k = 0; k < kLaneElems; ++k) {
-                    if (e & (1u << k)) ytile[pos] = tj[k];
-                    pos += (e >> k) & 1u;
+                    if (ends[4 * j + k]) ytile[pos] = tj[k];
+                    pos += ends[4 * j + k] ? 1 : 0;
                 }
             } else {
                 carry_step = wave_sum(((p[4 * j] + p[4 * j + 1]) + p[4 * j + 2]) + p[4 * j + 3]) + carry_step;
@@ -457,7 +491,16 @@ __device__ __forceinline__ void slices_group(
         // ceil(n_rows/64) load/store pairs per slice instead of mostly-empty predicated ones (the output phase cost
         // 25-30 % that way).
         const bool held = LOOKBACK && (deferred || rolling);   // the slice's first row is stored later, with its chain
-        for (int i = lane; i < n_rows; i += 64) {
+        if (!LOOKBACK) {
+            out_t0 = lane < n_rows ? ytile[lane] : 0.0f;
+            out_t1 = lane + 64 < n_rows ? ytile[lane + 64] : 0.0f;
+            out_b0 = bpre0; out_b1 = bpre1;       // still in flight: consumed behind the next iteration's wait
+            out_d0 = lane < n_rows ? (unsigned)(row_first + lane) << 2 : kNoAccess;
+            out_d1 = lane + 64 < n_rows ? (unsigned)(row_first + lane + 64) << 2 : kNoAccess;
+            out_carry = carry_step;
+            out_dc = lane == 0 ? (unsigned)cur << 2 : kNoAccess;
+        }
+        for (int i = LOOKBACK ? lane : lane + 128; i < n_rows; i += 64) {
             const float tt = ytile[i];
             const unsigned dst = (held && i == 0) ? kNoAccess : (unsigned)(row_first + i) << 2;
             if (HAS_BETA) {
@@ -472,7 +515,11 @@ __device__ __forceinline__ void slices_group(
                 __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(alpha * tt), ry, dst, 0, 0);
             }
         }
-        if (!LOOKBACK && lane == 0) store_float(carry + cur, carry_step);
+    }
+    if (!LOOKBACK) {      // the stores of this wavefront's last slice
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * out_t0 + beta * out_b0 : alpha * out_t0), ry, out_d0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * out_t1 + beta * out_b1 : alpha * out_t1), ry, out_d1, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(out_carry), rc, out_dc, 0, 0);
     }
     if (LOOKBACK && pend_slice >= 0) {    // the cut row of this wavefront's last slice
         const float chain = lookback_chain(lb, mbox, first, pend_slice, pend_len, lane);
@@ -687,16 +734,16 @@ __device__ __forceinline__ void batched_group(
             val[4 * j + 2] = i2f((int)w.v[j].z); val[4 * j + 3] = i2f((int)w.v[j].w);
         }
         int r0[kSliceSteps];
-        unsigned ends = 0;
+        bool ends[kE];
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             int below = 0, total = 0;
 #pragma unroll
             for (int k = 0; k < kLaneElems; ++k) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64((c[4 * j + k] & kRowEndBit) != 0);
+                ends[4 * j + k] = (c[4 * j + k] & kRowEndBit) != 0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ends[4 * j + k]);
                 below += lanes_below(m);
                 total += __builtin_popcountll(m);
-                ends |= (c[4 * j + k] >> 31) << (4 * j + k);
             }
             r0[j] = row + below;
             row += total;
@@ -748,17 +795,16 @@ __device__ __forceinline__ void batched_group(
             for (int j = 0; j < kSliceSteps; ++j) {
                 const float pj[kLaneElems] = {val[4 * j] * xg[4 * j], val[4 * j + 1] * xg[4 * j + 1], val[4 * j + 2] * xg[4 * j + 2], val[4 * j + 3] * xg[4 * j + 3]};
                 float tj[kLaneElems];
-                scan_step(pj, (ends >> (4 * j)) & 0xfu, carry_step, tj);
+                scan_step(pj, ends[4 * j], ends[4 * j + 1], ends[4 * j + 2], ends[4 * j + 3], carry_step, tj);
                 t[4 * j] = tj[0]; t[4 * j + 1] = tj[1]; t[4 * j + 2] = tj[2]; t[4 * j + 3] = tj[3];
             }
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
-                const unsigned e = (ends >> (4 * j)) & 0xfu;
                 int pos = r0[j] - row_first;
 #pragma unroll
                 for (int k = 0; k < kLaneElems; ++k) {
-                    if (e & (1u << k)) ytile[pos] = t[4 * j + k];
-                    pos += (e >> k) & 1u;
+                    if (ends[4 * j + k]) ytile[pos] = t[4 * j + k];
+                    pos += ends[4 * j + k] ? 1 : 0;
                 }
             }
             for (int i = lane; i < n_rows; i += 64) {
@@ -1133,22 +1179,29 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
             for (int j = 0; j < kSliceSteps; ++j) {
                 const float4 q = st4[j * 64];
                 const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
-                const unsigned e = (ends >> (4 * j)) & 0xfu;
+                bool e[kLaneElems];
                 int below = 0, total = 0;
 #pragma unroll
                 for (int k = 0; k < kLaneElems; ++k) {
-                    const unsigned long long mk = __builtin_amdgcn_ballot_w64((e >> k) & 1u);
+                    e[k] = ((ends >> (4 * j + k)) & 1u) != 0;
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(e[k]);
                     below += lanes_below(mk);
                     total += __builtin_popcountll(mk);
                 }
                 float tj[kLaneElems];
-                scan_step(pj, e, carry_step, tj);
-                int r = row + below;
+                scan_step(pj, e[0], e[1], e[2], e[3], carry_step, tj);
+                // the row ends of a step are distinct rows (and a row ends once per block): the four read-modify-writes
+                // are independent -- all reads, then all writes, one LDS round trip instead of four
+                int r[kLaneElems];
+                float a[kLaneElems];
+                r[0] = row + below;
 #pragma unroll
-                for (int k = 0; k < kLaneElems; ++k) {
-                    if (e & (1u << k)) acc[r] = acc[r] + tj[k];
-                    r += (e >> k) & 1u;
-                }
+                for (int k = 1; k < kLaneElems; ++k) r[k] = r[k - 1] + (e[k - 1] ? 1 : 0);
+#pragma unroll
+                for (int k = 0; k < kLaneElems; ++k) a[k] = e[k] ? acc[r[k]] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < kLaneElems; ++k)
+                    if (e[k]) acc[r[k]] = a[k] + tj[k];
                 row += total;
             }
             if (lane == 0) tails[c] = carry_step;
