@@ -1113,108 +1113,126 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
     const int4 tile = load_int4(M.tiles + tile_index);
     const int row0 = tile.x, n_rows = tile.y, block_begin = tile.z, n_blocks = tile.w;
 
-    // the first slice of the first block is requested before anything else
+    // the first two slices a wavefront has in the first block are requested before anything else: a wavefront keeps TWO
+    // slice buffers (slices `wave` and `wave + n_waves` of a block) and both are requested one block ahead, so phase A
+    // never waits for HBM (with one buffer the second slice of every block was requested and waited for inside phase A)
     int4 blk = load_int4(M.blocks + 2 * (size_t)block_begin);
-    TtsSlice w;
-    int cb = 0;
-    if (n_blocks > 0 && wave < blk.y) {
-        tts_request(w, words, blk.x + wave, lane);
-        cb = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave);
+    TtsSlice wA, wB;
+    int cbA = 0, cbB = 0;
+    if (n_blocks > 0) {
+        if (wave < blk.y) { tts_request(wA, words, blk.x + wave, lane); cbA = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave); }
+        if (wave + n_waves < blk.y) { tts_request(wB, words, blk.x + wave + n_waves, lane); cbB = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave + n_waves); }
     }
     for (int i = threadIdx.x; i < n_rows; i += blockDim.x) acc[i] = 0.0f;
     __syncthreads();
+
+    // phase A for one slice: gathers, products -> staging, the request that reuses the buffer (next >= 0)
+    auto phase_a = [&](TtsSlice& w, int& cb, int next) {
+        const int base = __builtin_amdgcn_readfirstlane(cb) << 2;
+        float xv[kE];
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            xv[4 * j + 0] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].x >> 16) << 2, base, 0));
+            xv[4 * j + 1] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].y >> 16) << 2, base, 0));
+            xv[4 * j + 2] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].z >> 16) << 2, base, 0));
+            xv[4 * j + 3] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].w >> 16) << 2, base, 0));
+        }
+        // products -> staging[slot] (the transposition), THEN the request that reuses the buffer: the slots are read from
+        // the buffer itself (16 registers less than keeping them across the request; two buffers + 16 products fit 128)
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            staging[w.m[j].x & 0xffffu] = i2f((int)w.v[j].x) * xv[4 * j + 0];
+            staging[w.m[j].y & 0xffffu] = i2f((int)w.v[j].y) * xv[4 * j + 1];
+            staging[w.m[j].z & 0xffffu] = i2f((int)w.v[j].z) * xv[4 * j + 2];
+            staging[w.m[j].w & 0xffffu] = i2f((int)w.v[j].w) * xv[4 * j + 3];
+        }
+        asm volatile("" ::: "memory");
+        if (next >= 0) {
+            tts_request(w, words, next, lane);
+            cb = *(const HISPMV_GLOBAL int*)(M.col_base + next);
+        }
+    };
+    // phase B for one chunk of 1024 staged products in row-major order
+    auto phase_b = [&](int c, int2 ci, unsigned ends) {
+        int row = __builtin_amdgcn_readfirstlane(ci.x);
+        const float4* st4 = (const float4*)(staging + c * kTtsChunkSlots) + lane;
+        float carry_step = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kSliceSteps; ++j) {
+            const float4 q = st4[j * 64];
+            const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
+            bool e[kLaneElems];
+            int below = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < kLaneElems; ++k) {
+                e[k] = ((ends >> (4 * j + k)) & 1u) != 0;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(e[k]);
+                below += lanes_below(mk);
+                total += __builtin_popcountll(mk);
+            }
+            float tj[kLaneElems];
+            scan_step(pj, e[0], e[1], e[2], e[3], carry_step, tj);
+            // the row ends of a step are distinct rows (and a row ends once per block): the four read-modify-writes
+            // are independent -- all reads, then all writes, one LDS round trip instead of four
+            int r[kLaneElems];
+            float a[kLaneElems];
+            r[0] = row + below;
+#pragma unroll
+            for (int k = 1; k < kLaneElems; ++k) r[k] = r[k - 1] + (e[k - 1] ? 1 : 0);
+#pragma unroll
+            for (int k = 0; k < kLaneElems; ++k) a[k] = e[k] ? acc[r[k]] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < kLaneElems; ++k)
+                if (e[k]) acc[r[k]] = a[k] + tj[k];
+            row += total;
+        }
+        if (lane == 0) tails[c] = carry_step;
+    };
 
     for (int b = 0; b < n_blocks; ++b) {
         const int slice_begin = __builtin_amdgcn_readfirstlane(blk.x), n_slices = __builtin_amdgcn_readfirstlane(blk.y);
         const int chunk_begin = __builtin_amdgcn_readfirstlane(blk.z), n_chunks = __builtin_amdgcn_readfirstlane(blk.w);
         int4 nxt = int4{0, 0, 0, 0};
         if (b + 1 < n_blocks) nxt = load_int4(M.blocks + 2 * (size_t)(block_begin + b + 1));
-        // ---- phase A: column order --------------------------------------------------------------------------------
-        for (int s = wave; s < n_slices; s += n_waves) {
-            const int base = __builtin_amdgcn_readfirstlane(cb) << 2;
-            float xv[kE];
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                xv[4 * j + 0] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].x >> 16) << 2, base, 0));
-                xv[4 * j + 1] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].y >> 16) << 2, base, 0));
-                xv[4 * j + 2] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].z >> 16) << 2, base, 0));
-                xv[4 * j + 3] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].w >> 16) << 2, base, 0));
-            }
-            float p[kE];
-            unsigned slot[kE];
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                p[4 * j + 0] = i2f((int)w.v[j].x) * xv[4 * j + 0]; slot[4 * j + 0] = w.m[j].x & 0xffffu;
-                p[4 * j + 1] = i2f((int)w.v[j].y) * xv[4 * j + 1]; slot[4 * j + 1] = w.m[j].y & 0xffffu;
-                p[4 * j + 2] = i2f((int)w.v[j].z) * xv[4 * j + 2]; slot[4 * j + 2] = w.m[j].z & 0xffffu;
-                p[4 * j + 3] = i2f((int)w.v[j].w) * xv[4 * j + 3]; slot[4 * j + 3] = w.m[j].w & 0xffffu;
-            }
-#pragma unroll
-            for (int i = 0; i < kE; ++i) asm volatile("" : "+v"(p[i]));
-            asm volatile("" ::: "memory");
-            // the next slice of this wavefront: in this block, or its first one in the next block (in flight across phase B)
-            if (s + n_waves < n_slices) {
-                tts_request(w, words, slice_begin + s + n_waves, lane);
-                cb = *(const HISPMV_GLOBAL int*)(M.col_base + slice_begin + s + n_waves);
-            } else if (wave < nxt.y) {
-                tts_request(w, words, nxt.x + wave, lane);
-                cb = *(const HISPMV_GLOBAL int*)(M.col_base + nxt.x + wave);
-            }
-#pragma unroll
-            for (int i = 0; i < kE; ++i) staging[slot[i]] = p[i];
+        // what phase B and the tail pass of THIS block read from memory leaves now: it is older than the gathers, so it has
+        // arrived when they have (loaded behind the barrier, every wavefront sat out a memory latency there -- and, the
+        // loads counting in order, the arrival of the next block's slices as well)
+        int2 ciA = int2{0, 0}, ciB = int2{0, 0}, ciT = int2{0, 0};
+        unsigned endsA = 0, endsB = 0;
+        if (wave < n_chunks) {
+            ciA = load_int2(M.chunk_info + chunk_begin + wave);
+            endsA = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + wave) * 64 + lane);
         }
-        if (wave >= n_slices && wave < nxt.y) {     // a wavefront without a slice in this block still prefetches for the next
-            tts_request(w, words, nxt.x + wave, lane);
-            cb = *(const HISPMV_GLOBAL int*)(M.col_base + nxt.x + wave);
+        if (wave + n_waves < n_chunks) {
+            ciB = load_int2(M.chunk_info + chunk_begin + wave + n_waves);
+            endsB = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + wave + n_waves) * 64 + lane);
+        }
+        if (wave == 0 && lane < n_chunks) ciT = load_int2(M.chunk_info + chunk_begin + lane);
+        // ---- phase A: column order --------------------------------------------------------------------------------
+        const bool more = wave + 2 * n_waves < n_slices;       // a third slice in this block (partly filled slices): rare
+        if (wave < n_slices) phase_a(wA, cbA, wave < nxt.y ? nxt.x + wave : -1);
+        else if (wave < nxt.y) { tts_request(wA, words, nxt.x + wave, lane); cbA = *(const HISPMV_GLOBAL int*)(M.col_base + nxt.x + wave); }
+        if (wave + n_waves < n_slices) {
+            phase_a(wB, cbB, more ? slice_begin + wave + 2 * n_waves : (wave + n_waves < nxt.y ? nxt.x + wave + n_waves : -1));
+            for (int s = wave + 2 * n_waves; s < n_slices; s += n_waves)
+                phase_a(wB, cbB, s + n_waves < n_slices ? slice_begin + s + n_waves : (wave + n_waves < nxt.y ? nxt.x + wave + n_waves : -1));
+        } else if (wave + n_waves < nxt.y) {
+            tts_request(wB, words, nxt.x + wave + n_waves, lane); cbB = *(const HISPMV_GLOBAL int*)(M.col_base + nxt.x + wave + n_waves);
         }
         __syncthreads();
         // ---- phase B: row-major order -----------------------------------------------------------------------------
-        for (int c = wave; c < n_chunks; c += n_waves) {
-            const int2 ci = load_int2(M.chunk_info + chunk_begin + c);
-            int row = __builtin_amdgcn_readfirstlane(ci.x);
-            const unsigned ends = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + c) * 64 + lane);
-            const float4* st4 = (const float4*)(staging + c * kTtsChunkSlots) + lane;
-            float carry_step = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kSliceSteps; ++j) {
-                const float4 q = st4[j * 64];
-                const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
-                bool e[kLaneElems];
-                int below = 0, total = 0;
-#pragma unroll
-                for (int k = 0; k < kLaneElems; ++k) {
-                    e[k] = ((ends >> (4 * j + k)) & 1u) != 0;
-                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(e[k]);
-                    below += lanes_below(mk);
-                    total += __builtin_popcountll(mk);
-                }
-                float tj[kLaneElems];
-                scan_step(pj, e[0], e[1], e[2], e[3], carry_step, tj);
-                // the row ends of a step are distinct rows (and a row ends once per block): the four read-modify-writes
-                // are independent -- all reads, then all writes, one LDS round trip instead of four
-                int r[kLaneElems];
-                float a[kLaneElems];
-                r[0] = row + below;
-#pragma unroll
-                for (int k = 1; k < kLaneElems; ++k) r[k] = r[k - 1] + (e[k - 1] ? 1 : 0);
-#pragma unroll
-                for (int k = 0; k < kLaneElems; ++k) a[k] = e[k] ? acc[r[k]] : 0.0f;
-#pragma unroll
-                for (int k = 0; k < kLaneElems; ++k)
-                    if (e[k]) acc[r[k]] = a[k] + tj[k];
-                row += total;
-            }
-            if (lane == 0) tails[c] = carry_step;
-        }
+        if (wave < n_chunks) phase_b(wave, ciA, endsA);
+        if (wave + n_waves < n_chunks) phase_b(wave + n_waves, ciB, endsB);
+        for (int c = wave + 2 * n_waves; c < n_chunks; c += n_waves)
+            phase_b(c, load_int2(M.chunk_info + chunk_begin + c), *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + c) * 64 + lane));
         __syncthreads();
         // rows cut by a chunk boundary: the chunk that holds the row end added its own part; the tails of the chunks
-        // before it follow here, in chunk order (one lane per chunk; a block has at most 28 chunks)
+        // before it follow here, in chunk order (one lane per chunk; a block has at most 48 chunks)
         if (wave == 0 && lane < n_chunks) {
-            const int2 ci = load_int2(M.chunk_info + chunk_begin + lane);
-            if (ci.y > 0) {
+            if (ciT.y > 0) {
                 float s = 0.0f;
-                for (int k = lane - ci.y; k < lane; ++k) s += tails[k];
-                acc[ci.x] = acc[ci.x] + s;
+                for (int k = lane - ciT.y; k < lane; ++k) s += tails[k];
+                acc[ciT.x] = acc[ciT.x] + s;
             }
         }
         blk = nxt;
