@@ -1106,6 +1106,7 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
     float* const staging = xs + M.acc_floats;
     float* const tails = staging + M.staging_floats;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform: table reads become scalar loads
     const int n_waves = blockDim.x >> 6;
     constexpr int kE = kSliceSteps * kLaneElems;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, M.cols * 4, 0x00020000);
@@ -1200,11 +1201,11 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         int2 ciA = int2{0, 0}, ciB = int2{0, 0}, ciT = int2{0, 0};
         unsigned endsA = 0, endsB = 0;
         if (wave < n_chunks) {
-            ciA = load_int2(M.chunk_info + chunk_begin + wave);
+            ciA = load_int2(M.chunk_info + chunk_begin + wave_u);
             endsA = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + wave) * 64 + lane);
         }
         if (wave + n_waves < n_chunks) {
-            ciB = load_int2(M.chunk_info + chunk_begin + wave + n_waves);
+            ciB = load_int2(M.chunk_info + chunk_begin + wave_u + n_waves);
             endsB = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + wave + n_waves) * 64 + lane);
         }
         if (wave == 0 && lane < n_chunks) ciT = load_int2(M.chunk_info + chunk_begin + lane);

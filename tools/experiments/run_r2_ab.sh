@@ -10,7 +10,7 @@ import json,sys
 d=json.load(open(f"gpurun_out/r2ab/details_{sys.argv[1]}.json"))
 print(sys.argv[1], d["summary"]["ms_per_step"], d["summary"]["roofline"]["frac"])
 for r in d["per_matrix"]:
-    if "28s/0KiB" in r["plan"]: print(f'{r["name"]:16s} {r["us"]:8.1f} us {r["alg_gbs"]:8.1f} GB/s {r["plan"]}')
+    if "28s/0KiB" in r["plan"] or r["nnz"] < 3000000: print(f'{r["name"]:16s} {r["us"]:8.1f} us (b2b {r.get("us_back_to_back", 0):6.1f}) {r["alg_gbs"]:8.1f} GB/s {r["plan"]}')
 PY
 done
 timeout -k 10 300 python3 bench.py --workload powerlaw --no-cpu-baseline --details $O/details_powerlaw.json > $O/bench_powerlaw.log 2>&1

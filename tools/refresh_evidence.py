@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""After tools/run_r2_m.sh has run on the GPU box (gpurun merges its output into gpurun_out/): copies the figures the
+"""After tools/evidence_pass.sh has run on the GPU box (gpurun merges its output into gpurun_out/): copies the figures the
 documents cite into profiles/ and regenerates the generated block of DESIGN.md ('results:begin' .. 'results:end').
 
     tools/refresh_evidence.py r2        # round tag: profiles/r2_*"""
@@ -52,12 +52,13 @@ lines = [
 if hbm:
     lines.append(f"rocprofv3 (`profiles/{tag}_summary.md`): HBM traffic {hbm / 1e6:.0f} MB per step against {alg / 1e6:.0f} MB algorithmic "
                  f"({hbm / alg:.2f}×: the 6-byte elements read less than the definition counts).")
-lines += ["", "Per matrix, each timed alone between two HIP events with the largest matrix streamed in between (cold Infinity Cache);",
+lines += ["", "Per matrix, each timed alone between two HIP events with the largest matrix streamed in between (cold Infinity Cache; GFLOP/s and",
+          "GB/s from that time), and as the average of 20 launches back to back (the reference's `rp_time` loop, `spmv-host.cpp:120-154`);",
           "plan = threads / slices per workgroup / LDS window / column tiles / share of compact (6-byte) slices; `1024t/28s/0KiB` = tile "
           "stream (28-slice blocks):", "",
-          "| matrix (stand-in family) | rows | nnz | µs | GFLOP/s | alg. GB/s | % of 8 TB/s | plan |", "|---|---:|---:|---:|---:|---:|---:|---|"]
+          "| matrix (stand-in family) | rows | nnz | µs | µs back to back | GFLOP/s | alg. GB/s | % of 8 TB/s | plan |", "|---|---:|---:|---:|---:|---:|---:|---:|---|"]
 for r in rows:
-    lines.append(f"| {r['name']} ({fam.get(r['name'], '?')}) | {r['rows']} | {r['nnz']} | {r['us']} | {r['gflops']} | {r['alg_gbs']} | "
+    lines.append(f"| {r['name']} ({fam.get(r['name'], '?')}) | {r['rows']} | {r['nnz']} | {r['us']} | {r.get('us_back_to_back', '–')} | {r['gflops']} | {r['alg_gbs']} | "
                  f"{r['pct_hbm_peak']} | {r['plan']} |")
 block = "<!-- results:begin (tools/refresh_evidence.py) -->\n" + "\n".join(lines) + "\n<!-- results:end -->"
 p = root / "DESIGN.md"
@@ -65,4 +66,10 @@ t = p.read_text()
 m = re.search(r"<!-- results:begin.*?<!-- results:end -->", t, re.S)
 assert m, "DESIGN.md has no results block"
 p.write_text(t[:m.start()] + block + t[m.end():])
+for w in ("dense", "model", "powerlaw"):
+    f = out / f"{tag}m" / f"details_{w}.json"
+    if f.exists():
+        sw = json.loads(f.read_text())["summary"]
+        shutil.copy(f, prof / f"{tag}_bench_details_{w}.json")
+        print(f"{w}: {sw['ms_per_step']} ms per step, {sw['value']} {sw['unit']}, frac {sw['roofline']['frac']}  (DESIGN.md 'Other workloads' is prose: update by hand)")
 print("profiles/ and DESIGN.md refreshed from", details)
