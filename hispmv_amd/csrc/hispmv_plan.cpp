@@ -24,13 +24,14 @@ struct BlockSet {
     std::vector<std::pair<uint32_t, int32_t>> ranked;   // {elements, block}
     std::vector<int32_t> blocks;     // result: staged blocks, ascending
     int64_t global_elems = 0;        // result: elements whose block is not staged
+    int64_t runs = 0;                // result: runs of consecutive staged blocks (= fragments, before the length cap)
 
     // Chooses the blocks slices [s0, s1) stage when at most `limit` blocks fit: all of them, or -- when up to
     // kSpill times as many are touched -- the `limit` most used ones (the other elements gather through L2).
     // Returns the number of staged blocks, or -1 when the group touches too many blocks for a window to pay.
     static constexpr int kSpill = 4;
     int64_t collect(const SliceStream& st, int64_t s0, int64_t s1, int64_t limit) {
-        blocks.clear(); global_elems = 0;
+        blocks.clear(); global_elems = 0; runs = 0;
         int lo = INT32_MAX, hi = -1;
         for (int64_t s = s0; s < s1; ++s) {
             lo = std::min(lo, st.hdr[s].x_base);
@@ -93,6 +94,7 @@ struct BlockSet {
         if (global_elems * 2 > n) return -1;              // the window would serve less than half of the gathers
         for (const auto& r : ranked) blocks.push_back(r.second);
         std::sort(blocks.begin(), blocks.end());
+        for (size_t k = 0; k < blocks.size(); ++k) runs += k == 0 || blocks[k] != blocks[k - 1] + 1;
         return (int64_t)blocks.size();
     }
 };
@@ -148,8 +150,8 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         }
         const int64_t ng = (n + G - 1) / G;
         const int64_t limit = c.cap / kFragBlock;
-        int64_t staged_blocks = 0, global_elems = 0;
-#pragma omp parallel reduction(+ : staged_blocks, global_elems)
+        int64_t staged_blocks = 0, global_elems = 0, runs = 0, two_way_elems = 0;
+#pragma omp parallel reduction(+ : staged_blocks, global_elems, runs, two_way_elems)
         {
             BlockSet bs;
 #pragma omp for schedule(dynamic, 16)
@@ -157,7 +159,10 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
                 const int64_t s0 = g * G, s1 = std::min<int64_t>(n, (g + 1) * G);
                 const int64_t k = bs.collect(st, s0, s1, limit);
                 if (k < 0) global_elems += (s1 - s0) * kSliceElems;
-                else { staged_blocks += k; global_elems += bs.global_elems; }
+                else {
+                    staged_blocks += k; global_elems += bs.global_elems; runs += bs.runs;
+                    if (k > 0 && bs.global_elems > 0) two_way_elems += (s1 - s0) * kSliceElems;
+                }
             }
         }
         // cost, with "every element gathers through L2" = 1: L2 requests (one per staged 64-byte block, one per
@@ -169,8 +174,13 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         // next to a short group does not pay -- R-MAT scale 20 with 16 slices per workgroup, 124 KiB staged per 128 KiB
         // of stream and half of the gathers still through L2, ran 343 us against 180 us gathering everything through L2
         const double staged_ratio = (double)staged_blocks * kFragBlock * 4.0 / ((double)n * kSliceElems * 8.0);
-        const double unhidden = (c.per_cu <= 2 ? 2.25 : 0.5) / (double)G;
-        const double cost = ((double)staged_blocks + (double)global_elems) / ((double)n * kSliceElems) +
+        // Fragments are staged one after the other by a wavefront, two dependent loads each (table entry, x): a window
+        // made of hundreds of short runs costs ~0.4 us per fragment and wavefront (ford2 as an unstructured band, 136
+        // fragments per 4-slice group of a 256-thread workgroup: 28.8 us against ~10 gathering through L2).  And a group
+        // with elements outside its window takes the two-way gather (window read + predicated L2 gather) for all of them.
+        const double frag_chain = 0.3 * ((double)runs / (double)ng) / (double)(c.threads / 64);
+        const double unhidden = ((c.per_cu <= 2 ? 2.25 : 0.5) + frag_chain) / (double)G;
+        const double cost = ((double)staged_blocks + (double)global_elems + 0.15 * (double)two_way_elems) / ((double)n * kSliceElems) +
                             0.2 * staged_ratio + unhidden +
                             0.3 * std::max(0, 16 - waves) / 16.0;
         if (cost < best_cost && cost < 0.8) { best_cost = cost; have = true; chosen = c; chosen_G = G; }

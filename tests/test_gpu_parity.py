@@ -185,17 +185,17 @@ def test_column_tiled_scattered_matrix(fpga):
 
 
 def test_window_of_most_used_blocks_with_l2_spill(pyhispmv_mod, monkeypatch):
-    """x slightly too large for one LDS window (45 000 uniformly used columns; column tiling switched off so that
-    the single-stream plan runs): the group's window holds its most used 64-byte blocks and the remaining elements
-    gather through L2 in the same pass.  Also a banded matrix with a few far-away couplings per row (blocks used
+    """x too large for one LDS window (88 % of the entries in 30 000 hot columns, the others anywhere in 400 000; column
+    tiling switched off so that the single-stream plan runs): the group's window holds its most used 64-byte blocks and
+    the remaining elements gather through L2 in the same pass.  Also a banded matrix with a few far-away couplings per row (blocks used
     once or twice stay out of the window).  Bit-exact against the wavefront model."""
     monkeypatch.setenv("HISPMV_COL_TILE_BYTES", "0")
     fpga = pyhispmv_mod.FpgaHandle(*HW)
     rng = np.random.default_rng(21)
     cases = []
-    rows, cols = 16000, 45000
+    rows, cols = 16000, 400000
     r = np.repeat(np.arange(rows, dtype=np.int32), 500)
-    cases.append((rows, cols, r, rng.integers(0, cols, r.size).astype(np.int32)))
+    cases.append((rows, cols, r, np.where(rng.random(r.size) < 0.88, rng.integers(0, 30000, r.size), rng.integers(30000, cols, r.size)).astype(np.int32)))
     rows, cols = 200000, 200000
     r = np.repeat(np.arange(rows, dtype=np.int32), 24)
     c = (r + rng.integers(-300, 300, r.size)) % cols

@@ -252,13 +252,18 @@ def test_fragment_windows_invert_to_the_original_columns():
     P = prep_from_coo(r, c, np.ones(r.size, np.float32), rows, rows)
     assert P.plan["lds_floats"] > 0 and P.groups[:, 1].max() > 1            # staged, with real multi-fragment windows
     _check_window_inversion(P)
-    # 45000 uniformly used columns: more than a window holds -> most used blocks staged, the rest flagged
-    rows2, cols2 = 16000, 45000
+    # 88 % of the entries in 30000 hot columns, the others spread over 400000: the hot blocks are staged (a few
+    # long fragments), the rest keep their column, flagged.  (45000 uniformly used columns -- a window of the ~2000 most
+    # used blocks in ~550 runs -- is no longer planned with a window: a wavefront stages its fragments one after the
+    # other, hispmv_plan.cpp.)
+    rows2, cols2 = 16000, 400000
     r2 = np.repeat(np.arange(rows2), 500)
-    c2 = rng.integers(0, cols2, r2.size)
+    c2 = np.where(rng.random(r2.size) < 0.88, rng.integers(0, 30000, r2.size), rng.integers(30000, cols2, r2.size))
     P2 = prep_from_coo(r2, c2, np.ones(r2.size, np.float32), rows2, cols2)
     assert P2.plan["lds_floats"] > 0 and P2.groups[:, 3].max() > 0
     _check_window_inversion(P2)
+    P3 = prep_from_coo(r2, rng.integers(0, 45000, r2.size), np.ones(r2.size, np.float32), rows2, 45000)
+    assert P3.plan["lds_floats"] == 0
 
 
 def _check_window_inversion(P):
