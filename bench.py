@@ -246,10 +246,11 @@ def load_powerlaw():
 class Runner:
     """One FpgaHandle, device vectors and a timing helper shared by the main measurement and the sub-measurements."""
 
-    def __init__(self, local_rank, world):
+    def __init__(self, local_rank, world, dist_on=False):
         import torch
         import pyhispmv
         self.torch, self.world = torch, world
+        self.dist_on = dist_on or world > 1
         self.dev = torch.device("cuda", local_rank)
         self.fpga = pyhispmv.FpgaHandle(HW[0], local_rank, *HW[1:])
         self.fpga.set_arena_bytes(200 << 30)
@@ -303,7 +304,7 @@ class Runner:
         return step
 
     def fence(self):
-        if self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             dist.barrier()
         self.torch.cuda.synchronize()
@@ -325,7 +326,7 @@ class Runner:
         t_wall = time.perf_counter() - t0
         t_dev = ev0.elapsed_time(ev1) * 1e-3
         self.fpga.synchronize()                       # raises if a bounded in-kernel wait (carry look-back) expired
-        if self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             tt = torch.tensor([t_wall, t_dev], dtype=torch.float64, device=self.dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -368,18 +369,21 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = None
-    if world > 1:
+    # HISPMV_BENCH_FORCE_DIST=1: initialise the process group, fences and the boundary exchange even with one rank (under
+    # torch.distributed.run with --nproc-per-node 1): the RCCL calls of the N > 1 path on a one-GPU box
+    dist_on = world > 1 or (under_torchrun and os.environ.get("HISPMV_BENCH_FORCE_DIST") == "1")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         backend = dist.get_backend()
-    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ranks_seen = dist.get_world_size() if dist_on else 1
 
     names = [n for n in args.matrices.split(",") if n]
     gb_sizes = [float(q) for q in args.strong_gb.split(",") if q]
-    R = Runner(local_rank, world)
+    R = Runner(local_rank, world, dist_on)
     fpga, sptr, stream = R.fpga, R.sptr, R.stream
     strong_main = world > 1 and args.scaling == "strong" and args.workload == "set"
 
@@ -405,7 +409,7 @@ def main():
     t_prep = R.add(mats)
 
     exch = None
-    if world > 1:
+    if dist_on:
         from hispmv_amd.dist import BoundaryExchange
         exch = BoundaryExchange(len(mats), R.dev)
 
@@ -593,7 +597,7 @@ def main():
             Path(args.details).write_text(json.dumps({"summary": out, "per_matrix": table}, indent=1) + "\n")
         print(json.dumps(out), flush=True)
     fpga.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

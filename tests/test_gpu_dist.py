@@ -1,5 +1,5 @@
 """Multi-GPU path with the real device pieces: world_size 2 and 3 ranks (all on GPU 0, `gloo` rendezvous -- a one-GPU
-box has no second device for RCCL) run their shard through hispmv_spmv_device and the boundary exchange through
+box has no second device for RCCL; the RCCL calls themselves run in a one-rank communicator) run their shard through hispmv_spmv_device and the boundary exchange through
 hispmv_boundary_pack / hispmv_boundary_apply around the all_gather (hispmv_amd/dist.py).  Same matrices and the same
 acceptance as the CPU test (tests/test_dist_gloo.py): every row has exactly one owner, y within 1e-5 of the fp64 result."""
 import os
@@ -17,13 +17,16 @@ from util import bwd_err
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, alpha, beta, out_q):
+def _worker(rank, world, port, alpha, beta, out_q, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import pyhispmv
-    from hispmv_amd.dist import BoundaryExchange, shard_csr
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":       # as bench.py initialises it
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pyhispmv
+    from hispmv_amd.dist import BoundaryExchange, shard_csr
     fpga = pyhispmv.FpgaHandle("none", 0, 24, 1, 1, 2, 5, True, False, True)
     mats = make_matrices()
     local = []
@@ -58,13 +61,27 @@ def _worker(rank, world, port, alpha, beta, out_q):
     dist.destroy_process_group()
 
 
+def test_boundary_exchange_through_rccl_single_rank():
+    """The `nccl` (= RCCL) code path of bench.py and dist.py on the one GPU of the test box: a communicator of one rank
+    (RCCL refuses two ranks on one device), initialised with device_id like bench.py, barrier, and the step's
+    all_gather_into_tensor on device tensors between the two boundary kernels.  Proves that the calls, dtypes and
+    devices are what RCCL accepts -- not that anything scales."""
+    if not dist.is_nccl_available():
+        pytest.skip("torch built without nccl/RCCL")
+    _run_world(1, "nccl")
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_spmv_on_device_with_boundary_kernels(world):
+    _run_world(world, "gloo")
+
+
+def _run_world(world, backend):
     alpha, beta = 0.85, -2.06
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in range(world))
