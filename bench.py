@@ -539,6 +539,30 @@ def main():
                                         "hbm_gbs_algorithmic": round(by * args.steps / tw / 1e9, 1), "scaling": "strong",
                                         "note": "whole-job rate of the same matrices nnz-split over n_gpus ranks (shard_csr); speed-up = value / the n_gpus = 1 value"}
 
+    if args.workload == "model" and rank == 0 and not args.no_extras:
+        # FpgaHandle.linear with 8 input vectors per call (apps/model_test.py --batch_size; fpga_handle.cpp:323-388): host
+        # buffers in and out, so the call is PCIe-inclusive; kernel_us = events around the launches alone (8 / 4 / 2
+        # vectors per pass over the matrix: gemv_rows_kernel<4,.,8>, spmv_slices_batched_kernel<.,.,4>)
+        rng = np.random.default_rng(99)
+        lin = []
+        for m in mats:
+            xs = rng.random(8 * m["cols"], dtype=np.float32)
+            bias = rng.random(m["rows"], dtype=np.float32)
+            fpga.linear(m["idx"], xs, bias)
+            ks, ws = [], []
+            for _ in range(7):
+                t1 = time.perf_counter()
+                fpga.linear(m["idx"], xs, bias)
+                ws.append(time.perf_counter() - t1)
+                ks.append(fpga.last_kernel_ms() * 1e-3)
+            k, w8 = float(np.median(ks)), float(np.median(ws))
+            lin.append({"name": m["name"], "vectors": 8, "kernel_us": round(k * 1e6, 2), "call_us_with_pcie": round(w8 * 1e6, 1),
+                        "gflops_kernel": round(8 * flops_of(m) / k / 1e9, 1),
+                        "matrix_passes_per_s_x_bytes_GBs": round(alg_bytes(m) * 8 / k / 1e9, 1)})
+        extras["linear_batch8"] = {"layers": lin, "note": "8 vectors per FpgaHandle.linear call; kernel_us is the device time of the launches, "
+                                   "call_us_with_pcie the whole call from host buffers; the last column counts the matrix bytes once per "
+                                   "vector, i.e. the rate a one-vector-per-pass kernel would need"}
+
     if rank == 0:
         if strong_main:
             total_flops = sum(M.flops(m["full_rows"], m["full_nnz"]) for m in mats) * args.steps
