@@ -500,7 +500,26 @@ __device__ __forceinline__ void slices_group(
             out_carry = carry_step;
             out_dc = lane == 0 ? (unsigned)cur << 2 : kNoAccess;
         }
-        for (int i = LOOKBACK ? lane : lane + 128; i < n_rows; i += 64) {
+        // rows 128.. of a short-row slice (fix-up variant): 256 rows per round, their bias loads issued together -- one wait
+        // per round instead of one per 64 rows (ASIC_680k: 260 rows per slice)
+        for (int i0 = 128; !LOOKBACK && i0 < n_rows; i0 += 256) {
+            float bb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (HAS_BETA) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 64 * u + lane;
+                    bb[u] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rb, i < n_rows ? (unsigned)(row_first + i) << 2 : kNoAccess, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u + lane;
+                const float tt = i < n_rows ? ytile[i] : 0.0f;
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * tt + beta * bb[u] : alpha * tt), ry,
+                                                      i < n_rows ? (unsigned)(row_first + i) << 2 : kNoAccess, 0, 0);
+            }
+        }
+        for (int i = lane; LOOKBACK && i < n_rows; i += 64) {
             const float tt = ytile[i];
             const unsigned dst = (held && i == 0) ? kNoAccess : (unsigned)(row_first + i) << 2;
             if (HAS_BETA) {
