@@ -103,8 +103,9 @@ struct hispmv_ctx {
     // tables, built on the first call and replayed afterwards
     struct BatchLaunch {
         int kind = 0;                                   // 0 slice kernels of one workgroup size, 1 fix-up of cut rows, 2 merge of column-tile
-                                                        // partial vectors, 3 transposed tile streams
+                                                        // partial vectors, 3 transposed tile streams, 4 dense overlay (GeMV)
         std::vector<TtsEntry> tts;                      // kind 3
+        std::vector<GemvEntry> gemv;                    // kind 4: the dense overlay handles of the call in one grid
         std::vector<const SpmvDeviceMatrix*> parts;     // kinds 0, 1
         std::vector<float*> ys;                         // kind 1: where each part's cut rows live (y or a partial vector)
         std::vector<int32_t> rows;                      // kind 2
@@ -880,6 +881,28 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         HIP_TRY(c, hipMemcpy(l.d_table, host, bytes, hipMemcpyHostToDevice));
         return HISPMV_OK;
     };
+    {   // dense overlay handles: one grid for all of them, the largest first (the small ones fill its tail; launched one
+        // after the other, the 512..2048-wide GeMVs of cpu/run_gemv.sh cost a launch latency each: 77 us for the five
+        // sizes against 56 us of streaming)
+        std::vector<int> dense;
+        for (int i = 0; i < n; ++i) if (c->mats[idx[i]]->dense) dense.push_back(i);
+        std::stable_sort(dense.begin(), dense.end(), [&](int a, int b) {
+            const Matrix& ma = *c->mats[idx[a]]; const Matrix& mb = *c->mats[idx[b]];
+            return (int64_t)ma.rows * ma.cols > (int64_t)mb.rows * mb.cols;
+        });
+        for (size_t k0 = 0; k0 < dense.size(); k0 += kMultiMax) {
+            hispmv_ctx::BatchLaunch l;
+            l.kind = 4;
+            for (size_t k = k0; k < std::min(dense.size(), k0 + (size_t)kMultiMax); ++k) {
+                const int i = dense[k];
+                const Matrix& m = *c->mats[idx[i]];
+                l.gemv.push_back(GemvEntry{m.d_dense, d_x[i], bias[i], d_y[i], m.rows, m.cols, beta, 0});
+            }
+            plan.launches.push_back(std::move(l));
+            const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().gemv.data(), plan.launches.back().gemv.size() * sizeof(GemvEntry));
+            if (rc0 != HISPMV_OK) return rc0;
+        }
+    }
     for (int geometry = 0; geometry < 2; ++geometry) {
         // transposed tile streams: their row tiles share one grid of 1024-thread workgroups per geometry (the launch's
         // LDS size is the largest of its entries: the half-LDS tiles must not ride with the tall ones)
@@ -1008,12 +1031,6 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
     const float* const* bias = d_bias;
     std::vector<const float*> no_bias;
     if (!bias) { no_bias.assign((size_t)n, nullptr); bias = no_bias.data(); }
-    for (int i = 0; i < n; ++i) {                       // dense overlay handles: one GeMV launch each
-        Matrix& m = *c->mats[idx[i]];
-        if (!m.dense) continue;
-        int rc = launch_matrix(c, m, d_x[i], bias[i], d_y[i], alpha, beta, s);
-        if (rc != HISPMV_OK) return rc;
-    }
     // the launches of this call signature: built once, replayed afterwards (beta enters the tables; alpha is a kernel argument)
     std::vector<uint64_t> key{(uint64_t)n, (uint64_t)__builtin_bit_cast(uint32_t, beta)};
     for (int i = 0; i < n; ++i) {
@@ -1033,12 +1050,15 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
             return rc;
         }
         plan = &c->batch_plans.back();
-        for (int i = 0; i < n; ++i) if (!c->mats[idx[i]]->dense) plan->stream_bytes += 8 * c->mats[idx[i]]->nnz;
+        for (int i = 0; i < n; ++i) {
+            const Matrix& mi = *c->mats[idx[i]];
+            plan->stream_bytes += mi.dense ? 4 * (int64_t)mi.rows * mi.cols : 8 * mi.nnz;
+        }
     }
     // main launches (kinds 0 and 3) are independent of each other: spread over the caller's stream and the side streams;
     // the fix-up and merge launches follow on the caller's stream behind a join
     int n_main = 0;
-    for (const auto& l : plan->launches) n_main += l.kind == 0 || l.kind == 3;
+    for (const auto& l : plan->launches) n_main += l.kind == 0 || l.kind == 3 || l.kind == 4;
     const int lanes = plan->stream_bytes >= c->batch_streams_min_bytes ? std::min(c->batch_streams, n_main) : 1;
     if (lanes > 1) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
@@ -1048,7 +1068,7 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
     bool joined = lanes <= 1;
     for (const auto& l : plan->launches) {
         hipError_t e = hipSuccess;
-        const bool is_main = l.kind == 0 || l.kind == 3;
+        const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
         hipStream_t ls = s;
         if (is_main && lanes > 1) { const int lane = k_main++ % lanes; ls = lane == 0 ? s : c->side[lane - 1]; }
         if (!is_main && !joined) {
@@ -1057,9 +1077,10 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
         }
         if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
         else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), (const TtsEntry*)l.d_table, alpha, ls);
+        else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
         else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
         else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
-        if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : "launch_merge_multi");
+        if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : "launch_merge_multi");
     }
     if (!joined)
         for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }

@@ -50,6 +50,12 @@ struct TtsEntry {                       // multi-matrix launch: one per matrix
     float beta; int32_t pad;
 };
 
+struct GemvEntry {                      // multi-matrix launch of the dense overlay: one per matrix
+    const float* W; const float* x; const float* bias; float* y;
+    int32_t rows, cols;
+    float beta; int32_t pad;
+};
+
 struct LookbackArgs {
     unsigned long long* gran;
     unsigned long long* ticket;
@@ -125,6 +131,9 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_ta
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
                        float* y, float alpha, float beta, hipStream_t stream);
+// the row blocks of `n` (<= kMultiMax) dense matrices in one grid (d_table: device copy of the entries); per matrix
+// bitwise equal to launch_gemv
+hipError_t launch_gemv_multi(const GemvEntry* entries, int n, const GemvEntry* d_table, float alpha, hipStream_t stream);
 // `vecs` vectors (x + v*cols -> y + v*rows, shared bias), 8/4/2/1 per pass over W; per vector bitwise equal to launch_gemv.
 hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64_t vecs, const float* x, const float* bias,
                                float* y, float alpha, float beta, hipStream_t stream);

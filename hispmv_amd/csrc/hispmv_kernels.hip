@@ -1333,12 +1333,12 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_ta
 // NV input vectors per pass over W (linear with num_vecs > 1): vector v is x + v*cols, its result y + v*rows; every
 // (row, vector) pair accumulates in exactly the order of the single-vector kernel, so the results are bitwise the same.
 template <int R, bool HAS_BETA, int NV>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ x,
-                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                        int rows, int cols, float alpha, float beta) {
+__device__ __forceinline__ void gemv_rows_body(const float* __restrict__ W, const float* __restrict__ x,
+                                               const float* __restrict__ bias, float* __restrict__ y,
+                                               int rows, int cols, float alpha, float beta, int block) {
     __shared__ float part[4][R][NV];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * R;
+    const int row0 = block * R;
     float acc[R][NV];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -1392,6 +1392,25 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
     }
 }
 
+template <int R, bool HAS_BETA, int NV>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ x,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int rows, int cols, float alpha, float beta) {
+    gemv_rows_body<R, HAS_BETA, NV>(W, x, bias, y, rows, cols, alpha, beta, (int)blockIdx.x);
+}
+
+// The dense handles of a batch call in one grid: block ranges per matrix (prefix.begin), largest matrix first so that the
+// small ones fill the tail.
+__global__ __launch_bounds__(256) void gemv_rows_multi_kernel(const GemvEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
+    int k = 0;
+#pragma unroll 1
+    while (k + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[k + 1]) ++k;
+    const GemvEntry e = table[k];
+    const int block = (int)((long long)blockIdx.x - prefix.begin[k]);
+    if (e.beta != 0.0f) gemv_rows_body<4, true, 1>(e.W, e.x, e.bias, e.y, e.rows, e.cols, alpha, e.beta, block);
+    else gemv_rows_body<4, false, 1>(e.W, e.x, e.bias, e.y, e.rows, e.cols, alpha, 0.0f, block);
+}
+
 template <int NV>
 static void launch_gemv_nv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
                            float* y, float alpha, float beta, hipStream_t stream) {
@@ -1408,6 +1427,20 @@ hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* 
     (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (rows <= 0) return hipSuccess;
     launch_gemv_nv<1>(W, rows, cols, x, bias, y, alpha, beta, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_multi(const GemvEntry* entries, int n, const GemvEntry* d_table, float alpha, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    if (n > kMultiMax) return hipErrorInvalidValue;
+    MultiPrefix prefix{};
+    prefix.n = n;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) { prefix.begin[i] = total; total += (entries[i].rows + 3) / 4; }
+    prefix.begin[n] = total;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gemv_rows_multi_kernel, dim3((unsigned)total), dim3(256), 0, stream, d_table, prefix, alpha);
     return hipGetLastError();
 }
 
