@@ -46,6 +46,7 @@ _f32p = C.POINTER(C.c_float)
 SIGNATURES = {
     "hispmv_prep_build_tts": (C.c_int, [_p, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "hispmv_prep_tts_array": (C.c_void_p, [_p, C.c_int]),
+    "hispmv_prep_tts_pieces": (C.c_int, [_p, C.POINTER(C.c_int64)]),
     "hispmv_version": (C.c_char_p, []),
     "hispmv_free_failures": (C.c_int64, []),
     "hispmv_boundary_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -322,9 +322,8 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             TtsStream t2 = build_tts(csr, 0, small);
             if (t2.lines_per_gather <= 16.0) ts = std::move(t2);
         }
-        // (a tile is one workgroup's work and a row is never split between tiles: a row far longer than the mean tile --
-        // Zipf row lengths at soc-Pokec's shape: one tile of 1.6 M slots against a mean of 134 K -- would be the critical
-        // path; such matrices keep the slice stream, which cuts rows at slice boundaries)
+        // (a tile is one workgroup's work; the packer cuts rows longer than a tile and a quarter into pieces and orders
+        // the tiles longest first, so this only rejects what is left: tiles capped by their row count next to full ones)
         const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
         const bool fewer_requests = ts.lines_per_gather / 64.0 + 0.1 < slice_requests;     // (+0.1: the two passes and barriers of a block)
         if (c->format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced && fewer_requests)) {
@@ -694,6 +693,17 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             TtsDeviceMatrix& d = p.tdev;
             d.words = dw; d.col_base = dcb; d.flags = dfl; d.chunk_info = (const int2*)dci; d.tiles = (const int4*)dt; d.blocks = (const int4*)db;
             d.n_tiles = (int32_t)ts.tiles.size(); d.rows = m.rows; d.cols = m.cols;
+            if (!ts.fix.empty()) {       // rows cut into pieces: carry slots + the slice stream's fix-up entries
+                const int32_t* dfix = nullptr;
+                if ((rc = upload(c, m, ts.fix.data(), ts.fix.size(), &dfix)) != HISPMV_OK) return rc;
+                void* carry = nullptr;
+                HIP_TRY(c, hipMalloc(&carry, (size_t)std::max(ts.n_carry, 1) * sizeof(float)));
+                m.allocs.push_back(carry);
+                HIP_TRY(c, hipMemsetAsync(carry, 0, (size_t)std::max(ts.n_carry, 1) * sizeof(float), c->stream));
+                d.fix = (const int4*)dfix; d.n_fix = (int32_t)(ts.fix.size() / 4); d.carry = (float*)carry;
+                // (the same three fields where the multi-matrix fix-up launch looks for them)
+                p.dev.fix_short = d.fix; p.dev.n_fix_short = d.n_fix; p.dev.carry = d.carry; p.dev.n_fix_long = 0;
+            }
             d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = kTtsThreads;
             d.staging_floats = ts.geometry.max_slots + 64;        // (the dummy slot of padding words sits behind the last real one)
             if (((size_t)d.acc_floats + (size_t)d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
@@ -972,16 +982,21 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         plan.launches.push_back(std::move(l));
         if ((rc = upload_table(plan.launches.back(), entries.data(), entries.size() * sizeof(MultiEntry))) != HISPMV_OK) return rc;
     }
-    for (size_t k = 0; k < refs.size(); k += kMultiMax) {       // fix-up of the cut rows
+    std::vector<Ref> fixrefs = refs;                            // + tile streams that cut long rows into pieces
+    for (int i = 0; i < n; ++i) {
+        const Matrix& m = *c->mats[idx[i]];
+        if (!m.dense && m.format == 1 && m.parts[0].tdev.n_fix > 0) fixrefs.push_back(Ref{i, 0});
+    }
+    for (size_t k = 0; k < fixrefs.size(); k += kMultiMax) {    // fix-up of the cut rows
         hispmv_ctx::BatchLaunch l;
         l.kind = 1;
         std::vector<MultiFixEntry> fix;
         bool any = false;
-        for (size_t q = k; q < std::min(refs.size(), k + kMultiMax); ++q) {
-            SpmvDeviceMatrix& d = dev_of(refs[q]);
-            fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(refs[q]), d.n_fix_short, 0});
+        for (size_t q = k; q < std::min(fixrefs.size(), k + kMultiMax); ++q) {
+            SpmvDeviceMatrix& d = dev_of(fixrefs[q]);
+            fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(fixrefs[q]), d.n_fix_short, 0});
             l.parts.push_back(&d);
-            l.ys.push_back(out_of(refs[q]));
+            l.ys.push_back(out_of(fixrefs[q]));
             any = any || d.n_fix_short > 0 || d.n_fix_long > 0;
         }
         if (!any) continue;
@@ -1227,9 +1242,15 @@ HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, 
     if (lines_per_gather) *lines_per_gather = t.lines_per_gather;
     return HISPMV_OK;
 }
+HISPMV_API int hispmv_prep_tts_pieces(const hispmv_prep* p, int64_t counts[2]) {
+    if (!p || !counts) return HISPMV_EINVAL;
+    counts[0] = (int64_t)p->tts.fix.size() / 4; counts[1] = p->tts.n_carry;
+    return HISPMV_OK;
+}
 HISPMV_API const void* hispmv_prep_tts_array(const hispmv_prep* p, int which) {
     if (!p) return nullptr;
     switch (which) {
+        case 6: return p->tts.fix.data();
         case 0: return p->tts.words.data();
         case 1: return p->tts.col_base.data();
         case 2: return p->tts.flags.data();

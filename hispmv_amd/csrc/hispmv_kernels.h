@@ -38,8 +38,11 @@ struct TtsDeviceMatrix {
     const int32_t* col_base = nullptr;  // per slice
     const uint16_t* flags = nullptr;    // per row-major chunk: 64 x u16 row-end bits
     const int2* chunk_info = nullptr;   // per chunk: {rows ending before it, chain_len}
-    const int4* tiles = nullptr;        // {row0, n_rows, block_begin, n_blocks}
+    const int4* tiles = nullptr;        // {row0, n_rows, block_begin, n_blocks}; row0 < 0: carry tile, its sum -> carry[-row0 - 1]
     const int4* blocks = nullptr;       // 2 x int4 per block: {slice_begin, n_slices, chunk_begin, n_chunks}, {n_slots, 0, 0, 0}
+    float* carry = nullptr;             // raw sums of the carry tiles (pieces of rows longer than two tiles)
+    const int4* fix = nullptr;          // {row, first carry, carries, 0} per such row: y[row] += alpha * sum (spmv_fixup_short_kernel)
+    int32_t n_fix = 0, pad = 0;
     int32_t n_tiles = 0, rows = 0, cols = 0;
     int32_t acc_floats = 0, staging_floats = 0;    // LDS: accumulators (max rows of a tile), staging (max slots of a block + dummy)
     int32_t threads = 512;                         // workgroup size (hispmv_tts.h: kTtsThreads)
@@ -126,6 +129,7 @@ hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const
 // Transposed tile stream: y = alpha*A*x + beta*bias in ONE launch (one workgroup of 1024 threads per row tile; no carry
 // buffers, no fix-up launch); launch_tts_multi: the tiles of `n` matrices in one grid (d_table: device copy of TtsEntry).
 hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream);
+// (launch_tts finishes the rows it cut into pieces with a second tiny launch; in a multi-matrix call they ride in launch_fixup_multi)
 hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_table, float alpha, hipStream_t stream);
 
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.

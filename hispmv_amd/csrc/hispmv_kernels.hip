@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, M.cols * 4, 0x00020000);
     const char* const words = (const char*)M.words;
     const int4 tile = load_int4(M.tiles + tile_index);
-    const int row0 = tile.x, n_rows = tile.y, block_begin = tile.z, n_blocks = tile.w;
+    const int row0 = tile.x, n_rows = tile.y, block_begin = tile.z, n_blocks = tile.w;      // row0 < 0: carry tile (one row)
 
     // the first two slices a wavefront has in the first block are requested before anything else: a wavefront keeps TWO
     // slice buffers (slices `wave` and `wave + n_waves` of a block) and both are requested one block ahead, so phase A
@@ -1259,6 +1259,10 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         // (the next phase A writes staging only; tails and acc are next touched behind the barrier that follows it)
     }
     __syncthreads();
+    if (row0 < 0) {         // a piece of a long row: its raw sum waits in carry[] for the fix-up launch
+        if (threadIdx.x == 0) *(HISPMV_GLOBAL float*)(M.carry + (-row0 - 1)) = acc[0];
+        return;
+    }
     for (int i = threadIdx.x; i < n_rows; i += blockDim.x) {
         const float t = acc[i];
         if (HAS_BETA) *(HISPMV_GLOBAL float*)(y + row0 + i) = alpha * t + beta * *(const HISPMV_GLOBAL float*)(bias + row0 + i);
@@ -1297,6 +1301,8 @@ hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bia
     if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     if (beta != 0.0f) hipLaunchKernelGGL(spmv_tts_kernel<true>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, bias, y, alpha, beta);
     else hipLaunchKernelGGL(spmv_tts_kernel<false>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, y, y, alpha, beta);
+    if (m.n_fix > 0)
+        hipLaunchKernelGGL(spmv_fixup_short_kernel, dim3((m.n_fix + 255) / 256), dim3(256), 0, stream, m.fix, m.n_fix, m.carry, y, alpha, 0LL, 0LL);
     return hipGetLastError();
 }
 

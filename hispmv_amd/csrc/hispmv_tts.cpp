@@ -120,17 +120,35 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     // tiles on large matrices so that every CU has one.
     const int64_t total = S.nnz + R;
     int64_t target = target_tile_elems > 0 ? target_tile_elems : std::max<int64_t>(total / geo.tiles_wanted, std::min(24 * kTtsChunk, geo.max_slots));
-    struct Range { int32_t r0, r1; };
+    struct Range { int32_t r0, r1; int64_t k0, k1; int32_t carry; };     // k0 >= 0: the piece [k0, k1) of row r0; carry >= 0: carry tile
     std::vector<Range> ranges;
+    // a row longer than a tile and a quarter is cut into pieces of about one tile (at most 33: the fix-up kernel for short
+    // chains adds them in order, one thread per row)
+    const int64_t split_above = target + target / 4;
+    constexpr int kMaxPieces = 33;
     for (int32_t r = 0; r < R;) {
+        const int64_t len0 = m.row_ptr[(size_t)r + 1] - m.row_ptr[r];
+        if (len0 > split_above) {
+            const int pieces = (int)std::min<int64_t>(kMaxPieces, (len0 + target - 1) / target);
+            const int64_t per = (len0 + pieces - 1) / pieces;
+            S.fix.insert(S.fix.end(), {r, S.n_carry, pieces - 1, 0});
+            for (int q = 0; q < pieces; ++q) {
+                const int64_t k0 = m.row_ptr[r] + q * per, k1 = std::min<int64_t>(m.row_ptr[(size_t)r + 1], k0 + per);
+                ranges.push_back(Range{r, r + 1, k0, k1, q + 1 < pieces ? S.n_carry++ : -1});
+            }
+            ++r;
+            continue;
+        }
         int32_t e = r;
         int64_t acc = 0;
         while (e < R && e - r < geo.max_rows) {
-            const int64_t len = std::max<int64_t>(m.row_ptr[(size_t)e + 1] - m.row_ptr[e], 1);
+            const int64_t raw = m.row_ptr[(size_t)e + 1] - m.row_ptr[e];
+            if (raw > split_above) break;                                    // (a long row starts its own tiles)
+            const int64_t len = std::max<int64_t>(raw, 1);
             if (e > r && acc + len > target) break;
             acc += len; ++e;
         }
-        ranges.push_back(Range{r, e});
+        ranges.push_back(Range{r, e, -1, -1, -1});
         r = e;
     }
     const size_t nt = ranges.size();
@@ -145,8 +163,12 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
             const Range rg = ranges[(size_t)t];
             const int n_rows = rg.r1 - rg.r0;
             el.clear();
-            for (int32_t r = rg.r0; r < rg.r1; ++r)
-                for (int64_t k = m.row_ptr[r]; k < m.row_ptr[(size_t)r + 1]; ++k) el.push_back(Elem{m.col[(size_t)k], r - rg.r0, m.val[(size_t)k]});
+            if (rg.k0 >= 0) {
+                for (int64_t k = rg.k0; k < rg.k1; ++k) el.push_back(Elem{m.col[(size_t)k], 0, m.val[(size_t)k]});
+            } else {
+                for (int32_t r = rg.r0; r < rg.r1; ++r)
+                    for (int64_t k = m.row_ptr[r]; k < m.row_ptr[(size_t)r + 1]; ++k) el.push_back(Elem{m.col[(size_t)k], r - rg.r0, m.val[(size_t)k]});
+            }
             std::stable_sort(el.begin(), el.end(), [](const Elem& a, const Elem& b) { return a.col < b.col; });   // rows stay ascending inside a column
             // blocks: greedy over the column-sorted list -- a block closes when its elements plus one filler for every
             // row it has not seen would exceed the slot budget
@@ -183,9 +205,10 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     }
     // concatenate the tiles
     int64_t n_slices = 0, n_chunks = 0;
+    std::vector<int64_t> tile_work(nt, 0);
     for (size_t t = 0; t < nt; ++t) {
         TileOut& o = outs[t];
-        TtsTile tile{ranges[t].r0, ranges[t].r1 - ranges[t].r0, (int32_t)S.blocks.size(), (int32_t)o.blocks.size()};
+        TtsTile tile{ranges[t].carry >= 0 ? -(ranges[t].carry + 1) : ranges[t].r0, ranges[t].r1 - ranges[t].r0, (int32_t)S.blocks.size(), (int32_t)o.blocks.size()};
         for (TtsBlock b : o.blocks) { b.slice_begin += (int32_t)n_slices; b.chunk_begin += (int32_t)n_chunks; S.blocks.push_back(b); }
         S.tiles.push_back(tile);
         n_slices += (int64_t)o.col_base.size(); n_chunks += (int64_t)o.chunk_info.size() / 2;
@@ -195,6 +218,18 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
         int64_t tile_slots = 0;
         for (const TtsBlock& b : o.blocks) tile_slots += b.n_slots;
         S.total_slots += tile_slots; S.max_tile_slots = std::max(S.max_tile_slots, tile_slots);
+        tile_work[t] = tile_slots;
+    }
+    // The tile table is the launch order (workgroup t takes tiles[t]; a CU holds one tile at a time): longest first, so
+    // that uneven tiles (row lengths far from uniform: 1.4 tiles per CU for Zipf lengths at soc-Pokec's shape) pack behind
+    // each other instead of a long one starting last.  Tiles of equal work keep their row order.
+    {
+        std::vector<size_t> order(nt);
+        for (size_t t = 0; t < nt; ++t) order[t] = t;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tile_work[a] / 4096 > tile_work[b] / 4096; });
+        std::vector<TtsTile> sorted(nt);
+        for (size_t t = 0; t < nt; ++t) sorted[t] = S.tiles[order[t]];
+        S.tiles.swap(sorted);
     }
     S.words.resize((size_t)n_slices * kTtsChunk * 8);
     S.col_base.reserve((size_t)n_slices); S.flags.reserve((size_t)n_chunks * 64); S.chunk_info.reserve((size_t)n_chunks * 2);

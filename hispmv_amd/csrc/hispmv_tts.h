@@ -16,7 +16,11 @@
 //     the lane that owns the row end (plain read-modify-write: rows are distinct inside a wave, cut rows are finished
 //     from a carry slot after a barrier).  No atomics: ds_add_f32 takes 193 cycles per wave instruction on gfx950
 //     (tools/lds_atomic_bench.hip), a compare-and-swap loop collapses under contention.  Results are deterministic.
-//   * every row of the tile owns >= 1 slot in every block (zero-valued filler), so rows need no index list.
+//   * every row of the tile owns >= 1 slot in every block (zero-valued filler), so rows need no index list;
+//   * a row longer than a tile and a quarter (Zipf row lengths: 1.6 M entries against 126 K per tile) is cut into <= 33 pieces of
+//     consecutive elements, each a tile of its own: the last piece is an ordinary one-row tile (y = alpha*sum + beta*bias),
+//     the others are CARRY TILES (row0 < 0) that write their raw sum to carry[-row0 - 1]; the fix-up kernel of the slice
+//     stream then adds alpha * (carry_0 + carry_1 + ...) to y[row] (entries {row, first carry, pieces - 1, 0} in `fix`).
 // Host-only code (packer); the kernel is in hispmv_kernels.hip.
 #pragma once
 #include <cstdint>
@@ -41,7 +45,7 @@ constexpr int kTtsSmallRows = 4 * 1024;
 struct TtsGeometry { int max_slots = kTtsMaxSlots, max_rows = kTtsMaxRows, tiles_wanted = 256; };
 
 struct TtsTile {           // 16 B per workgroup
-    int32_t row0;          // first row
+    int32_t row0;          // first row; < 0: carry tile (one piece of a long row), its sum goes to carry[-row0 - 1]
     int32_t n_rows;
     int32_t block_begin;   // first block of the tile
     int32_t n_blocks;
@@ -65,6 +69,8 @@ struct TtsStream {
     std::vector<uint16_t> flags;         // per chunk: 64 x u16, bit 4j+k of lane l = row end at slot 256j + 4l + k
     std::vector<int32_t> chunk_info;     // per chunk: {rows ending before the chunk (tile-local), chain_len: the first row
                                          //   ending in the chunk began this many chunks earlier}
+    std::vector<int32_t> fix;            // per row cut into pieces: {row, first carry, number of carries, 0} (the slice stream's FixEntry)
+    int32_t n_carry = 0;
     int64_t n_fillers = 0, n_pad_words = 0;
     double lines_per_gather = 0;         // distinct 128-byte lines of x per 64-lane gather (diagnostic / format choice)
     int max_rows = 0, max_slots = 0;
@@ -72,7 +78,7 @@ struct TtsStream {
     int64_t total_slots = 0, max_tile_slots = 0;   // a tile is one workgroup's work: a tile far above the mean (one very long row) is the critical path
     int64_t bytes() const {
         return (int64_t)words.size() + (int64_t)col_base.size() * 4 + (int64_t)flags.size() * 2 + (int64_t)chunk_info.size() * 4 +
-               (int64_t)tiles.size() * 16 + (int64_t)blocks.size() * 32;
+               (int64_t)tiles.size() * 16 + (int64_t)blocks.size() * 32 + (int64_t)fix.size() * 4 + (int64_t)n_carry * 4;
     }
 };
 

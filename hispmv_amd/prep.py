@@ -50,8 +50,10 @@ def _collect_tts(p, target, small: bool = False) -> dict:
         else:
             a = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
         return a.reshape(shape) if shape else a
+    pc = (C.c_int64 * 2)()
+    lib.hispmv_prep_tts_pieces(p, pc)
     return dict(n_tiles=tiles, n_blocks=blocks, n_slices=slices, n_chunks=chunks, fillers=fillers, pad_words=pads, max_rows=max_rows,
-                max_slots=max_slots, lines_per_gather=float(lpg.value),
+                max_slots=max_slots, lines_per_gather=float(lpg.value), n_carry=int(pc[1]), fix=arr(6, int(pc[0]) * 4, np.int32, (-1, 4)),
                 words=arr(0, slices * 2048, np.uint32, (-1, 2, 1024)), col_base=arr(1, slices, np.int32), flags=arr(2, chunks * 64, np.uint16, (-1, 64)),
                 chunk_info=arr(3, chunks * 2, np.int32, (-1, 2)), tiles=arr(4, tiles * 4, np.int32, (-1, 4)), blocks=arr(5, blocks * 8, np.int32, (-1, 8)))
 

@@ -210,12 +210,16 @@ int64_t hispmv_free_failures(void);
  * on the host: counts = {tiles, blocks, column-order slices of 1024 words, row-major chunks of 1024 slots, fillers,
  * padding words, max rows of a tile, max slots of a block}; arrays: 0 words (per slice 1024 x fp32 then 1024 x
  * {col_off:16 | slot:16}), 1 col_base (int32 per slice), 2 flags (64 x u16 per chunk), 3 chunk_info ({rows ending
- * before, chain_len} per chunk), 4 tiles ({row0, n_rows, block_begin, n_blocks}), 5 blocks (8 x int32: slice_begin,
+ * before, chain_len} per chunk), 4 tiles ({row0, n_rows, block_begin, n_blocks}; row0 < 0: carry tile), 5 blocks (8 x int32: slice_begin,
  * n_slices, chunk_begin, n_chunks, n_slots, 0, 0, 0).  target_tile_elems 0 = the loader's choice; small_geometry: 0 = tiles of
  * <= 8192 rows and blocks of <= 28 K slots (one workgroup per CU), 1 = <= 4096 rows / 13 K slots (two per CU: what the
  * loader takes when a gather of the tall geometry touches <= 8 lines; hispmv_matrix_info.group_slices = 28 or 13). */
 int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int small_geometry, int64_t counts[8], double* lines_per_gather);
 const void* hispmv_prep_tts_array(const hispmv_prep* p, int which);
+/* Rows longer than two tiles are cut into pieces, each a tile of its own; all but a row's last piece are carry tiles
+ * (tiles[.].row0 = -(carry index + 1)) whose sums a fix-up launch adds: counts = {rows cut, carry tiles}; array 6 of
+ * hispmv_prep_tts_array = {row, first carry, carries, 0} per row cut (int32 x 4). */
+int hispmv_prep_tts_pieces(const hispmv_prep* p, int64_t counts[2]);
 
 /* Library identification: "hispmv-amd <version> gfx950". */
 const char* hispmv_version(void);

@@ -72,7 +72,7 @@ def _load():
     lib.refpack_emulate.argtypes = [_p, _p, _p, C.c_float, C.c_float, _p]
     lib.emu_spmv.argtypes = [_p, _p, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int32, C.c_int]
     lib.emu_gemv.argtypes = [_p, C.c_int32, C.c_int32, _p, _p, C.c_float, C.c_float, _p]
-    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, _p, C.c_float, C.c_float, _p]
+    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p]
     return lib
 
 
@@ -307,7 +307,9 @@ def emu_tts(tts: dict, x, bias, alpha, beta, rows):
     ti, bl = _c(tts["tiles"], np.int32), _c(tts["blocks"], np.int32)
     xx, bb = _c(x, np.float32), _c(bias, np.float32)
     y = np.zeros(rows, dtype=np.float32)
-    lib.emu_tts(_ptr(w), _ptr(cb), _ptr(fl), _ptr(ci), _ptr(ti), _ptr(bl), tts["n_tiles"], _ptr(xx), _ptr(bb), alpha, beta, _ptr(y))
+    fx = _c(tts.get("fix", np.zeros((0, 4), np.int32)), np.int32)
+    lib.emu_tts(_ptr(w), _ptr(cb), _ptr(fl), _ptr(ci), _ptr(ti), _ptr(bl), tts["n_tiles"], _ptr(fx), fx.shape[0], int(tts.get("n_carry", 0)),
+                _ptr(xx), _ptr(bb), alpha, beta, _ptr(y))
     return y
 
 

@@ -295,7 +295,8 @@ def test_transposed_tile_stream_packer_and_its_model(shape):
     """The second device format (hispmv_tts.h), packed on the host and run through the CPU model of its kernel
     (oracle.emu_tts): every row of a tile owns a slot in every block, slots are a permutation of the block's row-major
     order, blocks respect their slot and slice budgets, and the product matches the fp64 accumulation -- including a heavy
-    row that spans many blocks, an empty matrix (fillers only) and slices cut short by the 16-bit column offsets."""
+    row that spans many blocks or is cut into pieces (carry tiles + fix-up entries), an empty matrix (fillers only) and
+    slices cut short by the 16-bit column offsets."""
     import oracle
     rows, cols, nnz, target = shape
     rng = np.random.default_rng(rows + nnz)
@@ -306,7 +307,21 @@ def test_transposed_tile_stream_packer_and_its_model(shape):
     P = prep_from_coo(r, c, v, rows, cols, tts=target)
     T = P.tts
     tiles, blocks = T["tiles"], T["blocks"]
-    assert tiles[:, 1].sum() == rows and tiles[0, 0] == 0 and np.all(tiles[1:, 0] == tiles[:-1, 0] + tiles[:-1, 1])
+    carry_tiles = tiles[:, 0] < 0                      # pieces of long rows (all but the last piece of a row)
+    norm = tiles[~carry_tiles]
+    norm = norm[np.argsort(norm[:, 0], kind="stable")]  # (the table is in launch order: longest tile first)
+    assert norm[:, 1].sum() == rows and norm[0, 0] == 0 and np.all(norm[1:, 0] == norm[:-1, 0] + norm[:-1, 1])
+    assert carry_tiles.sum() == T["n_carry"] and np.all(tiles[carry_tiles, 1] == 1)
+    assert np.array_equal(np.sort(-tiles[carry_tiles, 0] - 1), np.arange(T["n_carry"]))
+    work = np.array([blocks[t[2]:t[2] + t[3], 4].sum() for t in tiles])
+    assert np.all(work[:-1] // 4096 >= work[1:] // 4096)
+    if nnz >= 400000:
+        assert T["n_carry"] > 0                         # the heavy row (a quarter of the entries) of these cases is cut
+    used = np.zeros(T["n_carry"], int)
+    for row, first, n_c, _ in T["fix"]:                 # every carry belongs to exactly one row; the row's last piece is a one-row tile
+        assert 1 <= n_c <= 32 and np.any((norm[:, 0] == row) & (norm[:, 1] == 1))
+        used[first:first + n_c] += 1
+    assert np.all(used == 1)
     assert blocks[:, 4].max() <= 28 * 1024 and blocks[:, 1].max() <= 48 and np.all(blocks[:, 3] == (blocks[:, 4] + 1023) // 1024)
     assert blocks[:, 4].sum() == nnz + T["fillers"]
     for t in (0, len(tiles) - 1):                       # slots of a block: each real slot written exactly once
