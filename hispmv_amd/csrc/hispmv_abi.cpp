@@ -332,7 +332,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             p.tts = std::move(ts);
             p.st = SliceStream{}; p.dstream = DeviceStream{}; p.fix_short = {}; p.fix_long = {};
             m->format = 1; m->tts_lines_per_gather = p.tts.lines_per_gather;
-            m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = 0;
+            m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = (int64_t)p.tts.fix.size() / 4;
             m->device_bytes = p.tts.bytes();
             m->plan_threads = kTtsThreads; m->plan_group = p.tts.geometry.max_slots / kTtsChunk; m->plan_lds = 0;
             m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -158,7 +158,7 @@ typedef struct hispmv_matrix_info {
                                others take 8 bytes per element (32-bit meta) */
     int32_t format;         /* 0 = slice stream (rows in order, segmented scan); 1 = transposed tile stream (scattered short-row matrices:
                                row tiles with LDS accumulators, elements streamed sorted by column, transposed through LDS; n_slices then
-                               counts its 1024-word slices, n_split_rows is 0) */
+                               counts its 1024-word slices, n_split_rows the rows cut into pieces: longer than a tile and a quarter) */
     float tts_lines_per_gather;  /* format 1: distinct 128-byte lines of x per 64-lane gather (64 = no lane shares a line) */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);

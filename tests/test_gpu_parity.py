@@ -397,6 +397,52 @@ def test_multi_matrix_launch_matches_each_matrix_alone(fpga):
                                                   [m0["db"].data_ptr(), m1["db"].data_ptr()], [m0["dy"].data_ptr()] * 2), 1.0, 1.0)
 
 
+def test_dense_handles_of_a_batch_share_one_grid(fpga):
+    """hispmv_spmv_device_batch with several dense overlay handles (the sizes of cpu/run_gemv.sh:9-13 scaled down, a row
+    count that is not a multiple of the 4-row block, a width that is not a multiple of 4, the same handle twice): one
+    GeMV grid for all of them, largest first -- every y bit-identical to the handle launched alone and to the CPU model,
+    with and without bias, next to a sparse matrix in the same call."""
+    import torch
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda", 0)
+    shapes = [(64, 64), (1024, 1024), (301, 520), (2048, 512), (17, 4099), (1024, 1024)]
+    ds = []
+    for rows, cols in shapes:
+        W = rng.standard_normal((rows, cols), dtype=np.float32)
+        ds.append(dict(W=W, rows=rows, cols=cols, idx=fpga.create_dense_handle(W.flatten(), rows, cols)))
+    ds[5]["idx"] = ds[1]["idx"]; ds[5]["W"] = ds[1]["W"]            # the same dense handle twice (different vectors)
+    rs = rng.integers(0, 20000, 400000).astype(np.int32); cs = rng.integers(0, 20000, 400000).astype(np.int32)
+    vs = rng.random(400000, dtype=np.float32) - 0.5
+    i_sp = fpga.create_sparse_handle(rs, cs, vs, 20000, 20000)
+    fpga.load_matrices()
+    for d in ds:
+        d["x"], d["b"] = rng.random(d["cols"], dtype=np.float32), rng.random(d["rows"], dtype=np.float32)
+        d["dx"], d["db"] = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["b"]).to(dev)
+        d["dy"] = torch.full((d["rows"],), float("nan"), dtype=torch.float32, device=dev)
+    xs, bs = rng.random(20000, dtype=np.float32), rng.random(20000, dtype=np.float32)
+    dxs, dbs, dys = torch.from_numpy(xs).to(dev), torch.from_numpy(bs).to(dev), torch.zeros(20000, device=dev)
+    batch = fpga.prepare_batch([d["idx"] for d in ds[:3]] + [i_sp] + [d["idx"] for d in ds[3:]],
+                               [d["dx"].data_ptr() for d in ds[:3]] + [dxs.data_ptr()] + [d["dx"].data_ptr() for d in ds[3:]],
+                               [d["db"].data_ptr() for d in ds[:3]] + [dbs.data_ptr()] + [d["db"].data_ptr() for d in ds[3:]],
+                               [d["dy"].data_ptr() for d in ds[:3]] + [dys.data_ptr()] + [d["dy"].data_ptr() for d in ds[3:]])
+    for alpha, beta in ((ALPHA, BETA), (1.0, 0.0)):
+        for _ in range(2):
+            for d in ds:
+                d["dy"].fill_(float("nan"))
+            fpga.spmv_device_batch(batch, alpha, beta)
+            fpga.synchronize()
+            torch.cuda.synchronize()
+            for d in ds:
+                y = d["dy"].cpu().numpy()
+                alone = np.zeros(d["rows"], np.float32)
+                fpga.select_matrix(d["idx"])
+                fpga.run_kernel(d["x"], d["b"], alone, alpha, beta)
+                assert np.array_equal(y.view(np.uint32), alone.view(np.uint32)), (d["rows"], d["cols"], alpha, beta)
+                assert np.array_equal(y.view(np.uint32), oracle.emu_gemv(d["W"], d["x"], d["b"], alpha, beta).view(np.uint32))
+            y64, mag = csr_truth(rs, cs, vs, 20000, xs, bs, alpha, beta)
+            assert bwd_err(dys.cpu().numpy(), y64, mag) < TOL
+
+
 def test_csr_with_unsorted_rows_and_null_arrays(fpga):
     """hispmv_create_sparse_handle_from_csr: rows whose columns are not ascending (scipy: has_sorted_indices == False) are
     sorted on the way in -- same bits as the sorted matrix --, NULL column / value arrays with entries are rejected

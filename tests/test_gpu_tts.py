@@ -51,7 +51,8 @@ def test_tile_stream_matches_its_model_and_the_fp64_truth(case, monkeypatch):
     idx = h.create_sparse_handle(r, c, v, rows, cols)
     h.load_matrices()
     info = h.matrix_info(idx)
-    assert info["format"] == 1 and info["n_split_rows"] == 0 and info["group_slices"] in (13, 28)
+    assert info["format"] == 1 and info["group_slices"] in (13, 28)
+    assert info["n_split_rows"] == (2 if case == "empty_and_heavy_rows" else 0)      # rows cut into pieces (carry tiles + fix-up)
     P = prep_from_coo(r, c, v, rows, cols, tts=(0, info["group_slices"] == 13))     # the geometry the loader chose
     rp = P.row_ptr.astype(np.int32)
     h.select_matrix(idx)
