@@ -926,11 +926,19 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             l.kind = 3;
             return rc0;
         };
+        std::vector<int> order;                  // matrices with the longest tiles first (a CU holds one tile at a time)
         for (int i = 0; i < n; ++i) {
-            Matrix& m = *c->mats[idx[i]];
+            const Matrix& m = *c->mats[idx[i]];
             if (m.dense || m.format != 1) continue;
             const bool small = m.parts[0].tdev.staging_floats <= kTtsSmallSlots + 64;
-            if ((int)small != geometry) continue;
+            if ((int)small == geometry) order.push_back(i);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            const Matrix& ma = *c->mats[idx[a]]; const Matrix& mb = *c->mats[idx[b]];
+            return ma.n_elems / std::max(1, ma.parts[0].tdev.n_tiles) > mb.n_elems / std::max(1, mb.parts[0].tdev.n_tiles);
+        });
+        for (int i : order) {
+            Matrix& m = *c->mats[idx[i]];
             l.tts.push_back(TtsEntry{m.parts[0].tdev, d_x[i], bias[i], d_y[i], beta, 0});
             if ((int)l.tts.size() == kMultiMax) { const int rc0 = flush(); if (rc0 != HISPMV_OK) return rc0; }
         }
