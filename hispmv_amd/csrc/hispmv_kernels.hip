@@ -236,6 +236,58 @@ __device__ __forceinline__ void scan_step(const float (&p)[kLaneElems], bool e0,
     t[3] = (e0 | e1 | e2) ? s3 : cin + s3;
 }
 
+// LoadB: the x fragments {col_start, len, lds_off} of a group into its LDS window.  A wavefront takes every n_waves-th
+// fragment; its copies leave 8 at a time (512 float4 per round) and the next fragment's table entry travels with them.
+// (One float4 per iteration -- load, wait, ds_write -- made a 2048-float fragment eight memory round trips, and every
+// workgroup starts with this phase: PFlow_742 17 fragments on 16 wavefronts, ~10 us of a 48 us kernel.)
+// The float4s that reach past the end of x (at most the last 64-byte block) are read element-wise, zero beyond `cols`.
+__device__ __forceinline__ void stage_fragments(const int4* __restrict__ frags, int first, int count, const float* x, float* win,
+                                                int cols, int lane, int wave, int n_waves) {
+    constexpr int kU = 8;
+    int4 fr = wave < count ? load_int4(frags + first + wave) : int4{0, 0, 0, 0};
+    for (int f = wave; f < count; f += n_waves) {
+        const int col0 = __builtin_amdgcn_readfirstlane(fr.x), n4 = __builtin_amdgcn_readfirstlane(fr.y) >> 2;
+        const int off = __builtin_amdgcn_readfirstlane(fr.z);
+        if (f + n_waves < count) fr = load_int4(frags + first + f + n_waves);
+        const float4* src = (const float4*)(x + col0);
+        float4* dst = (float4*)(win + off);
+        const int inside = cols - col0 >= 4 * n4 ? n4 : (cols > col0 ? (cols - col0) >> 2 : 0);     // float4s entirely inside x
+        // rounds of 8, 2 or 1 wave-wide copies, by what is left of the fragment (wave-uniform: no divergence; short
+        // fragments -- one or two 64-byte blocks -- must not pay for eight loads)
+        int i0 = 0;
+        for (; inside - i0 > 128; i0 += 64 * kU) {
+            float4 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {          // (unconditional, index clamped: a predicate per load becomes a branch per load
+                const int i = i0 + 64 * u + lane;   //  and hipcc then waits for the loads before it)
+                v[u] = load_float4(src + (i < inside ? i : inside - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int i = i0 + 64 * u + lane;
+                if (i < inside) dst[i] = v[u];
+            }
+        }
+        if (inside - i0 > 64) {
+            const int ia = i0 + lane, ib = i0 + 64 + lane;
+            const float4 va = load_float4(src + ia), vb = load_float4(src + (ib < inside ? ib : inside - 1));
+            dst[ia] = va;
+            if (ib < inside) dst[ib] = vb;
+        } else if (inside - i0 > 0) {
+            const int ia = i0 + lane;
+            if (ia < inside) dst[ia] = load_float4(src + ia);
+        }
+        if (inside + lane < n4) {
+            const int i = inside + lane, c0 = col0 + 4 * i;
+            const HISPMV_GLOBAL float* xg = (const HISPMV_GLOBAL float*)x;
+            const float a0 = c0 + 0 < cols ? xg[c0 + 0] : 0.f;
+            const float a1 = c0 + 1 < cols ? xg[c0 + 1] : 0.f;
+            const float a2 = c0 + 2 < cols ? xg[c0 + 2] : 0.f;
+            dst[i] = float4{a0, a1, a2, 0.f};
+        }
+    }
+}
+
 // The work of one workgroup on group `group` of a matrix (the body of the slice kernels below), for a group stored
 // COMPACT (6 B per element) or wide (8 B): two instantiations, chosen per group by slices_body.
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool COMPACT>
@@ -300,22 +352,7 @@ __device__ __forceinline__ void slices_group(
     bool in_lds = false;
     if (USE_LDS) {
         in_lds = g.y > 0;                    // workgroup-uniform; 0 fragments = this group gathers through L2
-        for (int f = wave; f < g.y; f += n_waves) {
-            const int4 fr = load_int4(frags + g.x + f);  // {col_start, len, lds_off}: multiples of 16 floats
-            const float4* src = (const float4*)(x + fr.x);
-            float4* dst = (float4*)(xs + fr.z);
-            for (int i = lane; i < (fr.y >> 2); i += 64) {
-                // the last block of x may reach past cols: read it element-wise
-                if (fr.x + 4 * i + 3 < cols) dst[i] = load_float4(src + i);
-                else {      // (through the buffer descriptor: out-of-range reads return 0, no private array)
-                    const unsigned o = (unsigned)(fr.x + 4 * i) << 2;
-                    const float a0 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
-                    const float a1 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, o + 4, 0, 0));
-                    const float a2 = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, o + 8, 0, 0));
-                    dst[i] = float4{a0, a1, a2, 0.f};
-                }
-            }
-        }
+        stage_fragments(frags, g.x, g.y, x, xs, cols, lane, wave, n_waves);
         __syncthreads();
     }
 
@@ -719,22 +756,7 @@ __device__ __forceinline__ void batched_group(
         in_lds = g.y > 0;
         for (int v = 0; v < NV; ++v) {
             const float* xv = x + (size_t)v * cols;
-            for (int f = wave; f < g.y; f += n_waves) {
-                const int4 fr = load_int4(frags + g.x + f);
-                const float4* src = (const float4*)(xv + fr.x);
-                float4* dst = (float4*)(xs + v * lds_floats + fr.z);
-                for (int i = lane; i < (fr.y >> 2); i += 64) {
-                    if (fr.x + 4 * i + 3 < cols) dst[i] = load_float4(src + i);
-                    else {   // the last block of a vector may reach past its end: element-wise, zero beyond cols
-                        const int c0 = fr.x + 4 * i;
-                        const HISPMV_GLOBAL float* xg1 = (const HISPMV_GLOBAL float*)xv;
-                        const float a0 = c0 + 0 < cols ? xg1[c0 + 0] : 0.f;
-                        const float a1 = c0 + 1 < cols ? xg1[c0 + 1] : 0.f;
-                        const float a2 = c0 + 2 < cols ? xg1[c0 + 2] : 0.f;
-                        dst[i] = float4{a0, a1, a2, 0.f};
-                    }
-                }
-            }
+            stage_fragments(frags, g.x, g.y, xv, xs + v * lds_floats, cols, lane, wave, n_waves);
         }
         __syncthreads();
     }
