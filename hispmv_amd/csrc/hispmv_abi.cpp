@@ -56,6 +56,7 @@ struct Matrix {
     int64_t n_slices = 0, n_elems = 0, n_split = 0, compact_slices = 0;
     int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
     int format = 0;             // 0 slice stream, 1 transposed tile stream
+    int index = -1;             // position in the context's handle list
     double tts_lines_per_gather = 0;
     bool l2_tiles = false;      // the column tiles gather x through L2 (L2-sized tiles): pinned to XCD subsets in a batch call
     float* d_dense = nullptr;
@@ -339,7 +340,8 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             csr = Csr{};
             if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
             c->arena_used += m->device_bytes;
-            c->mats.push_back(std::move(m));
+            m->index = (int)c->mats.size();
+    c->mats.push_back(std::move(m));
             return (int)c->mats.size() - 1;
         }
     }
@@ -359,7 +361,10 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             Csr tile = column_tile(csr, first ? 0 : (int32_t)c0, last ? csr.cols : (int32_t)(c0 + tw));
             m->parts.emplace_back();
             m->parts.back().st = build_stream(tile);
-            finish_part(m->parts.back(), c->n_cus);
+            // the tiles of a matrix run in one grid: a two-window tile (resident plan: one long chunk per workgroup, its x
+            // window staged once) is planned for its share of the CUs
+            const int n_tiles = (int)((cmax - tbase) / tw + 1);
+            finish_part(m->parts.back(), used <= 2 * kMaxLdsFloats ? std::max(1, c->n_cus / std::max(1, n_tiles)) : c->n_cus);
         }
         // two tiles were meant to bring the x window into LDS: if they still gather through L2, tiling only
         // costs a launch and a read-modify-write of y -- go back to the single stream
@@ -391,6 +396,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
     c->arena_used += m->device_bytes;
+    m->index = (int)c->mats.size();
     c->mats.push_back(std::move(m));
     return (int)c->mats.size() - 1;
 }
@@ -407,8 +413,17 @@ int upload(hispmv_ctx* c, Matrix& m, const T* host, size_t count, const T** dev_
     return HISPMV_OK;
 }
 
+int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float* const* d_x, const float* const* d_bias,
+                      float* const* d_y, float alpha, float beta, hipStream_t s);
+
 int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
                   float alpha, float beta, hipStream_t s) {
+    if (!m.dense && m.format == 0 && m.parts.size() > 1 && m.index >= 0) {
+        // column tiles: all of them in ONE grid (+ one fix-up, one merge launch) through the batch machinery -- launched
+        // one after the other each tile had the chip to itself for half the work (mouse_gene 48 -> 40 us)
+        const int32_t idx = m.index;
+        return spmv_batch_locked(c, 1, &idx, &d_x, &d_bias, &d_y, alpha, beta, s);
+    }
     if (m.dense) {
         hipError_t e = launch_gemv(m.d_dense, m.rows, m.cols, d_x, d_bias, d_y, alpha, beta, s);
         if (e != hipSuccess) return hip_fail(c, e, "launch_gemv");
@@ -662,7 +677,8 @@ HISPMV_API int hispmv_create_dense_handle(hispmv_ctx* c, const float* vals, int3
         m->dense_host.assign(vals, vals + m->nnz);
         m->prep_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         c->arena_used += m->device_bytes;
-        c->mats.push_back(std::move(m));
+        m->index = (int)c->mats.size();
+    c->mats.push_back(std::move(m));
         return (int)c->mats.size() - 1;
     } catch (const std::bad_alloc&) { return fail(c, HISPMV_ENOMEM, "host out of memory"); }
 }
@@ -772,6 +788,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.lookback = (c->carry_mode == 1 || c->carry_mode == 3 || (c->carry_mode == 2 && resident && one_round) ||
                               (c->carry_mode == 5 && resident)) && mailbox_fits;
                 d.use_ticket = c->carry_mode == 3;
+                if (m.parts.size() > 1) { d.lookback = false; d.use_ticket = false; }      // column tiles share one grid: fix-up launch
             }
         }
         if (!m.dense && m.parts.size() > 1) {
@@ -1036,6 +1053,13 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
                                         const float* const* d_bias, float* const* d_y, float alpha, float beta, void* stream) {
     if (!c) return HISPMV_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
+    if (stream) c->user_stream = (hipStream_t)stream;
+    return spmv_batch_locked(c, n, idx, d_x, d_bias, d_y, alpha, beta, stream ? (hipStream_t)stream : c->stream);
+}
+
+namespace {
+int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float* const* d_x, const float* const* d_bias,
+                      float* const* d_y, float alpha, float beta, hipStream_t s) {
     if (n < 0 || (n > 0 && (!idx || !d_x || !d_y || (beta != 0.0f && !d_bias)))) return fail(c, HISPMV_EINVAL, "NULL argument");
     for (int i = 0; i < n; ++i) {
         if (idx[i] < 0 || idx[i] >= (int)c->mats.size()) return fail(c, HISPMV_EINVAL, "Matrix idx out of range");
@@ -1049,8 +1073,6 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
         }
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    if (stream) c->user_stream = (hipStream_t)stream;
     const float* const* bias = d_bias;
     std::vector<const float*> no_bias;
     if (!bias) { no_bias.assign((size_t)n, nullptr); bias = no_bias.data(); }
@@ -1109,6 +1131,7 @@ HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t*
         for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
     return HISPMV_OK;
 }
+}  // namespace
 
 HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
     if (!c) return HISPMV_EINVAL;
