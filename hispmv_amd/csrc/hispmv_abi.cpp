@@ -80,6 +80,7 @@ struct hispmv_ctx {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int batch_streams = 2;
+    bool batch_graphs = true;    // HISPMV_BATCH_GRAPH=0: no HIP graph replay of batch calls
     // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
     // the three model_test layers: 49.9 us on one stream, 63.1 on two; the 20-matrix set: 353 -> 344 us with two)
     int64_t batch_streams_min_bytes = 256ll << 20;
@@ -117,6 +118,10 @@ struct hispmv_ctx {
         std::vector<uint64_t> key;
         std::vector<BatchLaunch> launches;
         int64_t stream_bytes = 0;     // 8 B per entry of the call's sparse matrices: decides whether side streams pay
+        // HISPMV_BATCH_GRAPH=1 (experiment): the launches of a two-stream call captured once into a HIP graph and replayed
+        hipGraphExec_t graph = nullptr;
+        float graph_alpha = 0.0f;
+        int runs = 0;
     };
     std::vector<BatchPlan> batch_plans;
     // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
@@ -172,8 +177,10 @@ template <class T> void host_free(T*& p) {
 }
 
 void free_batch_plans(hispmv_ctx* c) {
-    for (auto& p : c->batch_plans)
+    for (auto& p : c->batch_plans) {
+        if (p.graph) { (void)hipGraphExecDestroy(p.graph); p.graph = nullptr; }
         for (auto& l : p.launches) dev_free(l.d_table);
+    }
     c->batch_plans.clear();
 }
 
@@ -552,6 +559,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
+    if (const char* env = std::getenv("HISPMV_BATCH_GRAPH")) c->batch_graphs = std::atoi(env) != 0;
     if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) { c->batch_streams = std::max(1, std::min(3, std::atoi(env))); c->batch_streams_min_bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate(side)");
@@ -1105,31 +1113,67 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     int n_main = 0;
     for (const auto& l : plan->launches) n_main += l.kind == 0 || l.kind == 3 || l.kind == 4;
     const int lanes = plan->stream_bytes >= c->batch_streams_min_bytes ? std::min(c->batch_streams, n_main) : 1;
-    if (lanes > 1) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-        for (int i = 0; i + 1 < lanes; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-    }
-    int k_main = 0;
-    bool joined = lanes <= 1;
-    for (const auto& l : plan->launches) {
-        hipError_t e = hipSuccess;
-        const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
-        hipStream_t ls = s;
-        if (is_main && lanes > 1) { const int lane = k_main++ % lanes; ls = lane == 0 ? s : c->side[lane - 1]; }
-        if (!is_main && !joined) {
-            for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
-            joined = true;
+    // the launches, as one function of the stream: main launches spread over the caller's stream and the side streams (forked
+    // from / joined to it with events), fix-up and merge behind the join
+    auto enqueue = [&]() -> int {
+        if (lanes > 1) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+            for (int i = 0; i + 1 < lanes; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
         }
-        if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
-        else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), (const TtsEntry*)l.d_table, alpha, ls);
-        else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
-        else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
-        else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
-        if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : "launch_merge_multi");
+        int k_main = 0;
+        bool joined = lanes <= 1;
+        for (const auto& l : plan->launches) {
+            hipError_t e = hipSuccess;
+            const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
+            hipStream_t ls = s;
+            if (is_main && lanes > 1) { const int lane = k_main++ % lanes; ls = lane == 0 ? s : c->side[lane - 1]; }
+            if (!is_main && !joined) {
+                for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
+                joined = true;
+            }
+            if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
+            else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), (const TtsEntry*)l.d_table, alpha, ls);
+            else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
+            else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
+            else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
+            if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : "launch_merge_multi");
+        }
+        if (!joined)
+            for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
+        return HISPMV_OK;
+    };
+    // A two-stream call is captured into a HIP graph the second time its signature is seen (the first run sets the
+    // kernels' attributes) and replayed from then on: the set's step 0.315-0.320 -> 0.309-0.310 ms -- the fork/join events
+    // of the two streams become graph edges.  HISPMV_BATCH_GRAPH=0 switches it off; a stream that is being captured by the
+    // caller, or a capture the runtime refuses, falls back to plain launches.
+    if (c->batch_graphs && lanes > 1) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
+        if (plan->graph && plan->graph_alpha == alpha) {
+            if (hipGraphLaunch(plan->graph, s) == hipSuccess) return HISPMV_OK;
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr;
+        }
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (plan->runs >= 1 && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone &&
+            hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t e_end = hipStreamEndCapture(s, &g);
+            if (rc != HISPMV_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
+            hipError_t e = e_end;
+            if (e == hipSuccess) e = hipGraphInstantiate(&plan->graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e == hipSuccess) e = hipGraphLaunch(plan->graph, s);
+            if (e == hipSuccess) { plan->graph_alpha = alpha; return HISPMV_OK; }
+            (void)hipGetLastError();
+            if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
+            c->batch_graphs = false;               // this runtime / stream does not take it: plain launches from here on
+        } else {
+            (void)hipGetLastError();
+        }
     }
-    if (!joined)
-        for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
-    return HISPMV_OK;
+    plan->runs++;
+    return enqueue();
 }
 }  // namespace
 
