@@ -75,13 +75,26 @@ def run_set(torch, mats, label):
             m["dy"] = torch.full((m["rows"],), float("nan"), dtype=torch.float32, device=dev)
         batch = h.prepare_batch([m["idx"] for m in mats], [m["dx"].data_ptr() for m in mats],
                                 [m["db"].data_ptr() for m in mats], [m["dy"].data_ptr() for m in mats])
-        for _ in range(2):                      # the second call reuses the cached device tables
+        # the second call reuses the cached device tables and (two-stream calls: the full sets) is captured into a HIP graph,
+        # the third and fourth replay it; then another alpha on the same tables (the graph is captured again)
+        for rep in range(5):
+            alpha = ALPHA if rep < 4 else np.float32(-1.75)
             for m in mats:
                 m["dy"].fill_(float("nan"))
             torch.cuda.synchronize()
-            h.spmv_device_batch(batch, ALPHA, BETA, 0)
+            h.spmv_device_batch(batch, alpha, BETA, 0)
             h.synchronize()
             torch.cuda.synchronize()
+            if rep == 4:
+                for m in sorted(mats, key=lambda q: -len(q["va"]))[:3]:
+                    check_y(f'{label}:{m["name"]}:batch:alpha2', m["dy"].cpu().numpy(), m["rp"], m["ci"], m["va"], m["cols"], m["x"], m["b"],
+                            float(alpha), BETA, mkl=False)
+                for m in mats:
+                    m["dy"].fill_(float("nan"))
+                torch.cuda.synchronize()
+                h.spmv_device_batch(batch, ALPHA, BETA, 0)          # back to the first alpha: captured once more, results checked below
+                h.synchronize()
+                torch.cuda.synchronize()
         for m in mats:
             yb = m["dy"].cpu().numpy()
             info = h.matrix_info(m["idx"])
