@@ -24,7 +24,7 @@ def first(pattern):
     return g[-1] if g else None
 
 
-out = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `tools/profile_round.sh " + tag + "` (bench.py --steps 5 --warmup 1, 20-matrix set)", ""]
+out = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `tools/profile_round.sh " + tag + "` (trace pass: bench.py --steps 30 --warmup 100; counter passes: --steps 5 --warmup 1; 20-matrix set)", ""]
 stats = first("trace/**/*kernel_stats.csv")
 if stats:
     rows = list(csv.DictReader(open(stats)))
@@ -52,7 +52,7 @@ if trace:
             spans.append((e0 - start) / 1e3)
             start = None
     if spans:
-        tail = spans[len(spans) // 2:]          # the later steps (past warm-up)
+        tail = spans[-30:] if len(spans) > 60 else spans[len(spans) // 2:]          # the timed steps (past warm-up)
         out += [f"Step span in the trace (first launch of a step to the end of its merge launch, last {len(tail)} steps): "
                 f"{sum(tail) / len(tail):.1f} us on average (min {min(tail):.1f}); under the profiler the chip clocks lower than in an "
                 "un-profiled run (MI355X_MICROARCH.md, DVFS), bench.py's HIP-event time is the un-profiled figure.", ""]
