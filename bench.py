@@ -54,10 +54,10 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the chip reaches its steady clocks after ~15 ms of load -- the set's step measures 0.315 ms in 20 steps behind
-    # 3 warm-up steps, 0.301 behind 50, 0.295-0.299 in 500 steps behind 100-200 (tools/experiments/run_r2_au.sh); 600 steps
+    # 3 warm-up steps, 0.301 behind 50, 0.295-0.299 in 500 steps behind 100-200 (tools/experiments/run_r2_au.sh); 700 steps
     # take 0.2 s
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", choices=["set", "powerlaw", "dense", "model"], default="set")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="what the main line measures when --gpus > 1")
     ap.add_argument("--strong-gb", type=str, default="", help="comma-separated sizes (GB of stream) of synthetic row-shardable "

@@ -24,7 +24,7 @@ def first(pattern):
     return g[-1] if g else None
 
 
-out = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `tools/profile_round.sh " + tag + "` (trace pass: bench.py --steps 30 --warmup 100; counter passes: --steps 5 --warmup 1; 20-matrix set)", ""]
+out = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `tools/profile_round.sh " + tag + "` (trace pass: bench.py --steps 30 --warmup 200; counter passes: --steps 5 --warmup 1; 20-matrix set)", ""]
 stats = first("trace/**/*kernel_stats.csv")
 if stats:
     rows = list(csv.DictReader(open(stats)))
