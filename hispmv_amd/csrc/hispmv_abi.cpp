@@ -136,6 +136,9 @@ struct hispmv_ctx {
     // the plan has no window, 2 auto = transposed tile stream when its gathers touch <= 32 cache lines of x per wave
     // instruction (HISPMV_FORMAT=slices|tts|auto)
     int format_mode = 2;
+    // geometry of a transposed tile stream: 0 the 8 K-row tiles always, 1 the tall geometry (two column parts of 16 K-row
+    // tiles) for every tile stream, 2 auto (HISPMV_TTS_GEOMETRY=standard|tall|auto)
+    int tts_geometry = 0;        // default: standard (measured: neither of the others is faster on soc-Pokec)
     int n_cus = 256;
 };
 
@@ -335,14 +338,55 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
         const bool fewer_requests = ts.lines_per_gather / 64.0 + 0.1 < slice_requests;     // (+0.1: the two passes and barriers of a block)
         if (c->format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced && fewer_requests)) {
-            Matrix::Part& p = m->parts[0];
-            p.is_tts = true;
-            p.tts = std::move(ts);
-            p.st = SliceStream{}; p.dstream = DeviceStream{}; p.fix_short = {}; p.fix_long = {};
-            m->format = 1; m->tts_lines_per_gather = p.tts.lines_per_gather;
-            m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = (int64_t)p.tts.fix.size() / 4;
-            m->device_bytes = p.tts.bytes();
-            m->plan_threads = kTtsThreads; m->plan_group = p.tts.geometry.max_slots / kTtsChunk; m->plan_lds = 0;
+            // The TALL geometry (hispmv_tts.h): when a gather of the 8 K-row tiles still touches many lines of x and x is
+            // larger than an XCD's L2, the matrix becomes two column parts of 16 K-row tiles -- the same number of tiles
+            // and elements per tile over half the column range (soc-Pokec: 23 -> 13 lines per gather), and in a batch
+            // call each part is pinned to four XCDs whose L2s then hold its half of x.  HISPMV_TTS_GEOMETRY=standard|tall|paired|auto
+            // (standard is the default: the gathers are bound by the cache's accesses per element, not by lines -- DESIGN.md 2.2).
+            std::vector<TtsStream> tall;
+            const bool paired = c->tts_geometry == 3;
+            const bool want_tall = c->tts_geometry == 1 || paired ||
+                                   (c->tts_geometry == 2 && ts.lines_per_gather > 16.0 && (int64_t)used * 4 > (4 << 20) && csr.rows >= 64 * kTtsTallRows);
+            if (want_tall) {
+                const std::vector<int32_t> cuts = tts_column_cuts(csr, kTtsTallParts);
+                double lines = 0; int64_t slices = 0;
+                bool ok = true;
+                for (int q = 0; q < kTtsTallParts && ok; ++q) {
+                    Csr part = csr_column_range(csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? csr.cols : cuts[(size_t)q]);
+                    tall.push_back(build_tts(part, 0, paired ? tts_paired_geometry(c->n_cus) : tts_tall_geometry(c->n_cus, kTtsTallParts)));
+                    const TtsStream& t = tall.back();
+                    lines += t.lines_per_gather * (double)t.col_base.size(); slices += (int64_t)t.col_base.size();
+                    ok = t.max_tile_slots <= 2 * (t.total_slots / std::max<int64_t>(1, (int64_t)t.tiles.size())) + 4096;
+                }
+                // (auto: only when it pays -- at least a quarter fewer lines per gather)
+                if (!ok || (c->tts_geometry == 2 && lines / (double)std::max<int64_t>(slices, 1) > 0.75 * ts.lines_per_gather)) tall.clear();
+            }
+            m->format = 1;
+            if (!tall.empty()) {
+                m->parts.clear();
+                double lines = 0;
+                for (TtsStream& t : tall) {
+                    m->parts.emplace_back();
+                    Matrix::Part& p = m->parts.back();
+                    p.is_tts = true;
+                    lines += t.lines_per_gather * (double)t.col_base.size();
+                    m->n_slices += (int64_t)t.col_base.size(); m->n_elems += t.nnz + t.n_fillers; m->n_split += (int64_t)t.fix.size() / 4;
+                    m->device_bytes += t.bytes();
+                    p.tts = std::move(t);
+                }
+                m->tts_lines_per_gather = lines / (double)std::max<int64_t>(m->n_slices, 1);
+                m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;     // partial vectors of parts t > 0
+                m->col_tile_width = tts_column_cuts(csr, kTtsTallParts)[0];
+            } else {
+                Matrix::Part& p = m->parts[0];
+                p.is_tts = true;
+                p.tts = std::move(ts);
+                p.st = SliceStream{}; p.dstream = DeviceStream{}; p.fix_short = {}; p.fix_long = {};
+                m->tts_lines_per_gather = p.tts.lines_per_gather;
+                m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = (int64_t)p.tts.fix.size() / 4;
+                m->device_bytes = p.tts.bytes();
+            }
+            m->plan_threads = m->parts[0].tts.geometry.threads; m->plan_group = m->parts[0].tts.geometry.max_slots / kTtsChunk; m->plan_lds = 0;
             m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             csr = Csr{};
             if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
@@ -425,7 +469,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
 
 int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
                   float alpha, float beta, hipStream_t s) {
-    if (!m.dense && m.format == 0 && m.parts.size() > 1 && m.index >= 0) {
+    if (!m.dense && m.parts.size() > 1 && m.index >= 0) {
         // column tiles: all of them in ONE grid (+ one fix-up, one merge launch) through the batch machinery -- launched
         // one after the other each tile had the chip to itself for half the work (mouse_gene 48 -> 40 us)
         const int32_t idx = m.index;
@@ -568,6 +612,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(fork)");
     if (const char* env = std::getenv("HISPMV_FORMAT"))
         c->format_mode = !std::strcmp(env, "slices") ? 0 : !std::strcmp(env, "tts") ? 1 : 2;
+    if (const char* env_g = std::getenv("HISPMV_TTS_GEOMETRY")) c->tts_geometry = !std::strcmp(env_g, "standard") ? 0 : !std::strcmp(env_g, "tall") ? 1 : !std::strcmp(env_g, "paired") ? 3 : 2;
     if (const char* env = std::getenv("HISPMV_PREP"))
         c->prep_mode = !std::strcmp(env, "host") ? 0 : !std::strcmp(env, "device") ? 1 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -704,7 +749,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             if ((rc = upload(c, m, m.dense_host.data(), m.dense_host.size(), &d)) != HISPMV_OK) return rc;
             m.d_dense = const_cast<float*>(d);
         } else if (m.format == 1) {
-            Matrix::Part& p = m.parts[0];
+          for (Matrix::Part& p : m.parts) {
             TtsStream& ts = p.tts;
             const uint8_t* dw = nullptr; const int32_t* dcb = nullptr; const uint16_t* dfl = nullptr; const int32_t* dci = nullptr;
             const TtsTile* dt = nullptr; const TtsBlock* db = nullptr;
@@ -728,11 +773,13 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 // (the same three fields where the multi-matrix fix-up launch looks for them)
                 p.dev.fix_short = d.fix; p.dev.n_fix_short = d.n_fix; p.dev.carry = d.carry; p.dev.n_fix_long = 0;
             }
-            d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = kTtsThreads;
+            d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = ts.geometry.threads;
+            d.zero_fill = ts.geometry.zero_fill ? 1 : 0;
             d.staging_floats = ts.geometry.max_slots + 64;        // (the dummy slot of padding words sits behind the last real one)
             if (((size_t)d.acc_floats + (size_t)d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             p.tts = TtsStream{};
+          }
         } else {
             for (auto& p : m.parts) {
                 const uint8_t* dw = nullptr; const SliceHdr* dh = nullptr; const FixEntry *fs = nullptr, *fl = nullptr;
@@ -938,9 +985,17 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             if (rc0 != HISPMV_OK) return rc0;
         }
     }
-    for (int geometry = 0; geometry < 2; ++geometry) {
-        // transposed tile streams: their row tiles share one grid of 1024-thread workgroups per geometry (the launch's
-        // LDS size is the largest of its entries: the half-LDS tiles must not ride with the tall ones)
+    std::vector<int> tts_classes;                // staging size = the geometry (hispmv_tts.h): small 13 K, standard 28 K, tall 23 K, paired 11 K
+    for (int i = 0; i < n; ++i) {
+        const Matrix& m = *c->mats[idx[i]];
+        if (m.dense || m.format != 1) continue;
+        const int cls = m.parts[0].tdev.staging_floats;
+        if (std::find(tts_classes.begin(), tts_classes.end(), cls) == tts_classes.end()) tts_classes.push_back(cls);
+    }
+    std::sort(tts_classes.begin(), tts_classes.end());
+    for (const int geometry : tts_classes) {
+        // transposed tile streams: their row tiles share one grid per geometry (the launch's workgroup size and LDS size
+        // are those of its entries: tiles of different geometries must not ride together)
         hispmv_ctx::BatchLaunch l;
         l.kind = 3;
         auto flush = [&]() -> int {
@@ -955,8 +1010,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         for (int i = 0; i < n; ++i) {
             const Matrix& m = *c->mats[idx[i]];
             if (m.dense || m.format != 1) continue;
-            const bool small = m.parts[0].tdev.staging_floats <= kTtsSmallSlots + 64;
-            if ((int)small == geometry) order.push_back(i);
+            if (m.parts[0].tdev.staging_floats == geometry) order.push_back(i);
         }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
             const Matrix& ma = *c->mats[idx[a]]; const Matrix& mb = *c->mats[idx[b]];
@@ -964,8 +1018,15 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         });
         for (int i : order) {
             Matrix& m = *c->mats[idx[i]];
-            l.tts.push_back(TtsEntry{m.parts[0].tdev, d_x[i], bias[i], d_y[i], beta, 0});
-            if ((int)l.tts.size() == kMultiMax) { const int rc0 = flush(); if (rc0 != HISPMV_OK) return rc0; }
+            if (l.tts.size() + m.parts.size() > (size_t)kMultiMax) { const int rc0 = flush(); if (rc0 != HISPMV_OK) return rc0; }
+            // the column parts of a tall-geometry matrix: one item, pinned to XCD subsets (part 0 writes y with the bias,
+            // part t > 0 alpha*A_t*x into the handle's partial vector: the merge launch adds it)
+            const bool pinned = pin && (m.parts.size() == 2 || m.parts.size() == 4);
+            for (size_t t = 0; t < m.parts.size(); ++t) {
+                l.tts.push_back(TtsEntry{m.parts[t].tdev, d_x[i], t == 0 ? bias[i] : nullptr, out_of(Ref{i, t}), t == 0 ? beta : 0.0f, 0});
+                if (!pinned) l.item_tiles.push_back(1);
+            }
+            if (pinned) l.item_tiles.push_back((uint8_t)m.parts.size());
         }
         const int rc0 = flush();
         if (rc0 != HISPMV_OK) return rc0;
@@ -1018,7 +1079,8 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
     std::vector<Ref> fixrefs = refs;                            // + tile streams that cut long rows into pieces
     for (int i = 0; i < n; ++i) {
         const Matrix& m = *c->mats[idx[i]];
-        if (!m.dense && m.format == 1 && m.parts[0].tdev.n_fix > 0) fixrefs.push_back(Ref{i, 0});
+        if (!m.dense && m.format == 1)
+            for (size_t t = 0; t < m.parts.size(); ++t) if (m.parts[t].tdev.n_fix > 0) fixrefs.push_back(Ref{i, t});
     }
     for (size_t k = 0; k < fixrefs.size(); k += kMultiMax) {    // fix-up of the cut rows
         hispmv_ctx::BatchLaunch l;
@@ -1049,7 +1111,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
     };
     for (int i = 0; i < n; ++i) {                               // merge of the column-tile partial vectors
         Matrix& m = *c->mats[idx[i]];
-        if (m.dense || m.format == 1 || m.parts.size() < 2) continue;
+        if (m.dense || m.parts.size() < 2) continue;
         merges.push_back(MultiMergeEntry{d_y[i], m.d_ypart, (long long)kMaxBatch * m.rows, (int32_t)m.parts.size() - 1, m.rows});
         merge_rows.push_back(m.rows);
         if ((int)merges.size() == kMultiMax && (rc = flush_merges()) != HISPMV_OK) return rc;
@@ -1132,7 +1194,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
                 joined = true;
             }
             if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
-            else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), (const TtsEntry*)l.d_table, alpha, ls);
+            else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const TtsEntry*)l.d_table, alpha, ls);
             else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
             else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
             else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
@@ -1308,7 +1370,15 @@ HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, 
     if (!p || !counts) return HISPMV_EINVAL;
     try {
         TtsGeometry geo;
-        if (small_geometry) { geo.max_slots = kTtsSmallSlots; geo.max_rows = kTtsSmallRows; geo.tiles_wanted = 512; }
+        if (small_geometry == 1) { geo.max_slots = kTtsSmallSlots; geo.max_rows = kTtsSmallRows; geo.tiles_wanted = 512; }
+        if (small_geometry >= 2) {         // 2 + q / 4 + q: column part q of the tall / paired geometry, as the loader builds it for a 256-CU device
+            const bool paired = small_geometry >= 4;
+            const int q = small_geometry - (paired ? 4 : 2);
+            if (q >= kTtsTallParts) { g_prep_err = "no such column part"; return HISPMV_EINVAL; }
+            const std::vector<int32_t> cuts = tts_column_cuts(p->csr, kTtsTallParts);
+            const Csr part = csr_column_range(p->csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? p->csr.cols : cuts[(size_t)q]);
+            p->tts = build_tts(part, target_tile_elems, paired ? tts_paired_geometry(256) : tts_tall_geometry(256, kTtsTallParts));
+        } else
         p->tts = build_tts(p->csr, target_tile_elems, geo);
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
     const TtsStream& t = p->tts;

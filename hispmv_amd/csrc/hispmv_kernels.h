@@ -42,7 +42,8 @@ struct TtsDeviceMatrix {
     const int4* blocks = nullptr;       // 2 x int4 per block: {slice_begin, n_slices, chunk_begin, n_chunks}, {n_slots, 0, 0, 0}
     float* carry = nullptr;             // raw sums of the carry tiles (pieces of rows longer than two tiles)
     const int4* fix = nullptr;          // {row, first carry, carries, 0} per such row: y[row] += alpha * sum (spmv_fixup_short_kernel)
-    int32_t n_fix = 0, pad = 0;
+    int32_t n_fix = 0;
+    int32_t zero_fill = 0;              // 1: rows absent from a block have no stream word, the staging is kept zero-filled (TtsGeometry::zero_fill)
     int32_t n_tiles = 0, rows = 0, cols = 0;
     int32_t acc_floats = 0, staging_floats = 0;    // LDS: accumulators (max rows of a tile), staging (max slots of a block + dummy)
     int32_t threads = 512;                         // workgroup size (hispmv_tts.h: kTtsThreads)
@@ -130,7 +131,10 @@ hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const
 // buffers, no fix-up launch); launch_tts_multi: the tiles of `n` matrices in one grid (d_table: device copy of TtsEntry).
 hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream);
 // (launch_tts finishes the rows it cut into pieces with a second tiny launch; in a multi-matrix call they ride in launch_fixup_multi)
-hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_table, float alpha, hipStream_t stream);
+// `item_parts` (n_items entries summing to n; NULL = all 1): 2 = the two column parts of one matrix, consecutive entries,
+// pinned to XCDs 0-3 / 4-7 so that an XCD's L2 holds one part's half of x.
+hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_parts, int n_items, const TtsEntry* d_table, float alpha,
+                            hipStream_t stream);
 
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,

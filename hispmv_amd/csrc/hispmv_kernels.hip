@@ -1166,6 +1166,11 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         if (wave + n_waves < blk.y) { tts_request(wB, words, blk.x + wave + n_waves, lane); cbB = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave + n_waves); }
     }
     for (int i = threadIdx.x; i < n_rows; i += blockDim.x) acc[i] = 0.0f;
+    // zero-fill geometry (hispmv_tts.h): rows absent from a block own a slot of its row-major order but no stream word --
+    // the staging is all zero whenever a phase A starts: zeroed here, and phase B writes zeros back over what it has read
+    const bool zero_fill = M.zero_fill != 0;
+    if (zero_fill)
+        for (int i = threadIdx.x; i < (M.staging_floats >> 2); i += blockDim.x) ((float4*)staging)[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
 
     // phase A for one slice: gathers, products -> staging, the request that reuses the buffer (next >= 0)
@@ -1202,6 +1207,7 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             const float4 q = st4[j * 64];
+            if (zero_fill) ((float4*)st4)[j * 64] = float4{0.0f, 0.0f, 0.0f, 0.0f};
             const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
             bool e[kLaneElems];
             int below = 0, total = 0;
@@ -1302,9 +1308,21 @@ __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __
     int k = 0;
 #pragma unroll 1
     while (k + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[k + 1]) ++k;
-    const TtsEntry e = table[k];          // (once per workgroup; every load in the body is cast to the global address space)
-    if (e.beta != 0.0f) tts_tile_body<true>(e.m, e.x, e.bias, e.y, alpha, e.beta, (int)(blockIdx.x - prefix.begin[k]));
-    else tts_tile_body<false>(e.m, e.x, e.y, e.y, alpha, 0.0f, (int)(blockIdx.x - prefix.begin[k]));
+    // An item with tiles[k] = 2 is the two column parts of one matrix (tall geometry, hispmv_tts.h): consecutive table
+    // entries pinned to XCDs 0-3 / 4-7 (blockIdx mod 8, as the slice kernel's pinned column tiles), so that an XCD's L2
+    // holds one part's half of x.
+    int tile = (int)(blockIdx.x - prefix.begin[k]);
+    int entry = prefix.first[k];
+    const int parts = prefix.tiles[k];
+    if (parts > 1) {
+        const int per = 8 / parts, res = tile & 7;
+        entry += res / per;
+        tile = (tile >> 3) * per + (res % per);
+    }
+    const TtsEntry e = table[entry];      // (once per workgroup; every load in the body is cast to the global address space)
+    if (tile >= e.m.n_tiles) return;      // (a part with fewer tiles than its sibling)
+    if (e.beta != 0.0f) tts_tile_body<true>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
+    else tts_tile_body<false>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
 }
 
 static size_t tts_lds_bytes(const TtsDeviceMatrix& m) { return ((size_t)m.acc_floats + (size_t)m.staging_floats + 64) * sizeof(float); }
@@ -1328,7 +1346,8 @@ hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bia
     return hipGetLastError();
 }
 
-hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_table, float alpha, hipStream_t stream) {
+hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_parts, int n_items, const TtsEntry* d_table, float alpha,
+                            hipStream_t stream) {
     (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
     if (n > kMultiMax) return hipErrorInvalidValue;
@@ -1338,16 +1357,27 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const TtsEntry* d_ta
         if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
         raised = true;
     }
+    if (!item_parts) n_items = n;
     MultiPrefix px{};
-    px.n = n;
+    px.n = n_items;
     long long g = 0;
     size_t lds = 0;
-    for (int i = 0; i < n; ++i) {
-        px.begin[i] = g; px.first[i] = (uint8_t)i; px.tiles[i] = 1;
-        g += entries[i].m.n_tiles;
-        lds = std::max(lds, tts_lds_bytes(entries[i].m));
+    int e = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const int parts = item_parts ? item_parts[k] : 1;
+        if ((parts != 1 && parts != 2 && parts != 4) || e + parts > n) return hipErrorInvalidValue;
+        if (parts > 1) g = (g + 7) & ~7LL;                 // a pinned set starts at a multiple of 8
+        px.begin[k] = g; px.first[k] = (uint8_t)e; px.tiles[k] = (uint8_t)parts;
+        long long most = 0;
+        for (int q = 0; q < parts; ++q, ++e) {
+            most = std::max<long long>(most, entries[e].m.n_tiles);
+            lds = std::max(lds, tts_lds_bytes(entries[e].m));
+        }
+        if (parts == 1) g += most;
+        else { const int per = 8 / parts; g += 8 * ((most + per - 1) / per); }
     }
-    px.begin[n] = g;
+    if (e != n) return hipErrorInvalidValue;
+    px.begin[n_items] = g;
     if (g > 0x7fffffffLL || lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     if (g > 0) hipLaunchKernelGGL(spmv_tts_multi_kernel, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     return hipGetLastError();

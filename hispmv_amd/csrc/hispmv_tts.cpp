@@ -71,7 +71,9 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
     const int32_t first_col = e1 > e0 ? el[e0].col : 0;
     // (cnt[] now holds each row's element count again)  fillers follow the elements: column -1 = "the base of whatever
     // slice it lands in" (offset 0: a valid column, the gather is a broadcast)
-    for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0) ws.push_back(W{-1, (uint32_t)start[(size_t)r], 0.0f});
+    // (zero_fill geometry: nothing is streamed for an absent row -- its slot of the zero-filled staging reads 0.0)
+    if (!geo.zero_fill)
+        for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0) ws.push_back(W{-1, (uint32_t)start[(size_t)r], 0.0f});
     size_t i = 0;
     while (i < ws.size()) {
         const int32_t base = (ws[i].col >= 0 ? ws[i].col : first_col) & ~31;          // 128-byte aligned
@@ -156,7 +158,7 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
 #pragma omp parallel
     {
         std::vector<Elem> el;
-        std::vector<int32_t> cnt((size_t)kTtsMaxRows), start((size_t)kTtsMaxRows), seen((size_t)kTtsMaxRows);
+        std::vector<int32_t> cnt((size_t)geo.max_rows), start((size_t)geo.max_rows), seen((size_t)geo.max_rows);
         std::vector<uint32_t> slot_of;
 #pragma omp for schedule(dynamic, 1)
         for (long long t = 0; t < (long long)nt; ++t) {
@@ -187,7 +189,7 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
                     if (sl_count == 0 || sl_fill == kTtsChunk || el[i].col - sl_base >= 65536) { n_sl = sl_count + 1; n_fill = 1; n_base = el[i].col & ~31; }
                     else n_fill = sl_fill + 1;
                     const int64_t fillers = n_rows - distinct - add_distinct;
-                    const int64_t extra = fillers - (kTtsChunk - n_fill);                   // fillers beyond the open slice's room
+                    const int64_t extra = geo.zero_fill ? 0 : fillers - (kTtsChunk - n_fill);   // filler words beyond the open slice's room
                     const int64_t total_slices = n_sl + (extra > 0 ? (extra + kTtsChunk - 1) / kTtsChunk : 0);
                     if ((int64_t)(i - b0 + 1) + fillers > geo.max_slots || total_slices > kTtsMaxBlockSlices) close = true;
                 }
@@ -247,6 +249,47 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     }
     S.lines_per_gather = gathers ? lines / (double)gathers : 0.0;
     return S;
+}
+
+std::vector<int32_t> tts_column_cuts(const Csr& m, int parts) {
+    std::vector<int32_t> cuts;
+    if (parts < 2) return cuts;
+    const int32_t n_bins = (m.cols + 31) / 32;
+    std::vector<int64_t> hist((size_t)n_bins, 0);
+    const int64_t nnz = m.nnz();
+    for (int64_t k = 0; k < nnz; ++k) hist[(size_t)(m.col[(size_t)k] >> 5)]++;
+    int64_t acc = 0;
+    int next = 1;
+    for (int32_t b = 0; b < n_bins && next < parts; ++b) {
+        acc += hist[(size_t)b];
+        while (next < parts && acc * parts >= nnz * next) { cuts.push_back((b + 1) * 32); ++next; }
+    }
+    while ((int)cuts.size() < parts - 1) cuts.push_back(m.cols);
+    return cuts;
+}
+
+Csr csr_column_range(const Csr& m, int32_t c0, int32_t c1) {
+    Csr t;
+    t.rows = m.rows; t.cols = m.cols;
+    t.row_ptr.assign((size_t)m.rows + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        t.row_ptr[(size_t)i + 1] = std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0);
+    }
+    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
+    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
+        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
+        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
+        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
+    }
+    return t;
 }
 
 }  // namespace hispmv

@@ -42,7 +42,29 @@ constexpr int kTtsMaxBlockSlices = 48;  // column-order slices of a block (the 1
 // waiting there): PFlow_742 as an unstructured band 81.9 -> 93.4 us, Si41Ge41H72 39.5 -> 48.0 us, boyd2 18.7 -> 14.6 us.
 constexpr int kTtsSmallSlots = 13 * 1024;
 constexpr int kTtsSmallRows = 4 * 1024;
-struct TtsGeometry { int max_slots = kTtsMaxSlots, max_rows = kTtsMaxRows, tiles_wanted = 256; };
+// A third geometry, the TALL one: 16 K rows and 23 K slots per tile (64 + 92 KiB of LDS), for matrices whose gathers touch
+// many lines of x with the 8 K-row tiles (soc-Pokec: 23 lines per gather).  Twice the rows over HALF the columns (the
+// matrix is cut into two column parts, each a tile stream of its own: part 0 writes y, part 1 a partial vector that the
+// merge launch adds) keeps the elements per tile and the number of tiles, and halves the column range a tile's elements
+// spread over: 9 lines per gather.  With that many rows a block of 23 K slots holds few elements per row, and one filler
+// WORD per absent row would be half the stream: in this geometry (`zero_fill`) an absent row still owns a slot of the
+// block's row-major order, but nothing is streamed for it -- the staging is zero when phase A starts (phase B writes
+// zeros back over what it has read), so the slot reads 0.0.
+constexpr int kTtsTallSlots = 23 * 1024;
+constexpr int kTtsTallRows = 16 * 1024;
+// A fourth, the PAIRED geometry: two 8-wavefront workgroups per CU, each with 8 K rows of accumulators and 11 K slots of
+// staging (2 x 78 KiB), again over two column parts so that the number of row tiles stays what the rows allow (a CU then
+// holds a tile of each part, or two of one).  Measured on soc-Pokec the tile stream is bound by two things that do not
+// overlap inside ONE workgroup: the texture addresser takes the lanes of a scattered gather one per cycle (34.3 M cache
+// accesses per launch for 32.4 M elements: 53 us of the 103 whatever the lines per gather are), and phase B is VALU work
+// behind a barrier.  Two independent workgroups per CU are in different phases most of the time.
+constexpr int kTtsPairedSlots = 11 * 1024;
+constexpr int kTtsPairedThreads = 512;
+struct TtsGeometry {
+    int max_slots = kTtsMaxSlots, max_rows = kTtsMaxRows, tiles_wanted = 256;
+    bool zero_fill = false;      // rows absent from a block own a slot but no stream word (the kernel keeps the staging zero-filled)
+    int threads = kTtsThreads;   // workgroup size
+};
 
 struct TtsTile {           // 16 B per workgroup
     int32_t row0;          // first row; < 0: carry tile (one piece of a long row), its sum goes to carry[-row0 - 1]
@@ -85,5 +107,23 @@ struct TtsStream {
 // Packs a CSR matrix (columns ascending per row).  `target_tile_elems`: elements per row tile (0 = chosen from the matrix
 // and the geometry).
 TtsStream build_tts(const Csr& m, int64_t target_tile_elems = 0, TtsGeometry geometry = TtsGeometry());
+
+// The column parts of the tall geometry: `parts` - 1 cut columns (ascending, multiples of 32) that split the ELEMENTS of
+// the matrix evenly (a histogram over the columns; a part is [cut[p-1], cut[p]) with cut[-1] = 0, cut[parts-1] = cols).
+std::vector<int32_t> tts_column_cuts(const Csr& m, int parts);
+// The tall geometry for a device with `n_cus` CUs and `parts` column parts (each part gets n_cus / parts tiles).
+inline TtsGeometry tts_tall_geometry(int n_cus, int parts) {
+    TtsGeometry g;
+    g.max_slots = kTtsTallSlots; g.max_rows = kTtsTallRows; g.tiles_wanted = n_cus / parts > 0 ? n_cus / parts : 1; g.zero_fill = true;
+    return g;
+}
+constexpr int kTtsTallParts = 2;
+inline TtsGeometry tts_paired_geometry(int n_cus) {
+    TtsGeometry g;
+    g.max_slots = kTtsPairedSlots; g.max_rows = kTtsMaxRows; g.tiles_wanted = n_cus; g.zero_fill = true; g.threads = kTtsPairedThreads;
+    return g;
+}
+// Columns [c0, c1) of a CSR matrix as a matrix of its own (same rows and width: column ids stay global, x is shared).
+Csr csr_column_range(const Csr& m, int32_t c0, int32_t c1);
 
 }  // namespace hispmv

@@ -71,10 +71,12 @@ def shard_csr(row_ptr, col_idx, values, world: int, rank: int) -> Shard:
     k1 = np.where(real == 0, k0, k1)
     cnt = k1 - k0
     loc = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
-    if cnt.sum():
-        idx = np.concatenate([np.arange(s, t) for s, t in zip(k0, k1) if t > s])
+    if cnt.sum():          # the rows' element ranges are adjacent in the global arrays: one contiguous slice
+        nz = np.nonzero(cnt)[0]
+        idx = slice(int(k0[nz[0]]), int(k1[nz[-1]]))
+        assert idx.stop - idx.start == int(cnt.sum())
     else:
-        idx = np.zeros(0, dtype=np.int64)
+        idx = slice(0, 0)
     return Shard(rank, world, b, e, r0, r1 - r0, loc, np.asarray(col_idx)[idx].astype(np.int32),
                  np.asarray(values)[idx].astype(np.float32), bool(eoff[r0] < b), bool(eoff[r1] > e))
 
@@ -137,13 +139,20 @@ class BoundaryExchange:
     "y" (the rank's local rows, device or CPU) and optionally "shard" (a Shard); entries without a shard
     are row-aligned blocks (nothing is cut) and contribute zeros -- the collective still runs, it is the
     path's exchange step.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the
-    CPU tests)."""
+    CPU tests).  With `world`/`rank` given explicitly the object touches no process group: it is one of the
+    virtual ranks of a LoopbackWorld (several ranks in one process, the all_gather a concatenation)."""
 
-    def __init__(self, n_mats: int, device):
+    def __init__(self, n_mats: int, device, world: int | None = None, rank: int | None = None):
         import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.torch = torch
+        self.loopback = world is not None
+        if self.loopback:
+            self.dist = None
+            self.world, self.rank = int(world), int(rank)
+        else:
+            import torch.distributed as dist
+            self.dist = dist
+            self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.device = device
         self.n = n_mats
         self.send = torch.zeros(n_mats, dtype=torch.float32, device=device)
@@ -151,23 +160,26 @@ class BoundaryExchange:
         self.ready = False
 
     def _all_gather(self, out, inp):
+        if self.loopback:
+            raise RuntimeError("a virtual rank has no collective of its own: drive it through LoopbackWorld.step")
         if self.dist.get_backend() == "gloo":
             parts = list(out.view(self.world, -1).unbind(0))
             self.dist.all_gather(parts, inp.reshape(-1))
         else:
             self.dist.all_gather_into_tensor(out, inp)
 
-    def _setup(self, mats):
-        torch = self.torch
+    def local_flags(self, mats) -> np.ndarray:
+        """flags[n, 3] = (head_open, tail_open, single_row) of this rank's shard of every matrix."""
         flags = np.zeros((self.n, 3), dtype=np.float32)
         for i, m in enumerate(mats):
             sh = m.get("shard")
             if sh is not None:
                 flags[i] = (sh.head_open, sh.tail_open, sh.n_rows == 1)
-        f = torch.from_numpy(flags.reshape(-1)).to(self.device)
-        allf = torch.zeros(self.world * f.numel(), dtype=torch.float32, device=self.device)
-        self._all_gather(allf, f)
-        allf = allf.cpu().numpy().reshape(self.world, self.n, 3)
+        return flags
+
+    def finish_setup(self, mats, flags: np.ndarray, allf: np.ndarray) -> None:
+        """allf[world, n, 3]: every rank's flags -> chain weights, tail mask, head list."""
+        torch = self.torch
         w = np.stack([chain_weights(allf[:, i, :], self.rank) for i in range(self.n)])   # [n, world]
         self.weights = torch.from_numpy(w).to(self.device)
         self.tail_mask = torch.from_numpy(flags[:, 1].copy()).to(self.device)
@@ -175,6 +187,14 @@ class BoundaryExchange:
         self.has_rows = [bool(m["y"].numel()) for m in mats]
         self.zero = torch.zeros((), dtype=torch.float32, device=self.device)
         self.ready = True
+
+    def _setup(self, mats):
+        torch = self.torch
+        flags = self.local_flags(mats)
+        f = torch.from_numpy(flags.reshape(-1)).to(self.device)
+        allf = torch.zeros(self.world * f.numel(), dtype=torch.float32, device=self.device)
+        self._all_gather(allf, f)
+        self.finish_setup(mats, flags, allf.cpu().numpy().reshape(self.world, self.n, 3))
 
     def _device_tables(self, mats):
         """Device path: pointer tables for hispmv_boundary_pack / hispmv_boundary_apply (include/hispmv.h): the last
@@ -200,34 +220,70 @@ class BoundaryExchange:
             self._device_tables(mats)
             self._stream = self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def run(self, mats, alpha: float = 1.0, prepared: bool = False) -> None:
-        """After every rank's local SpMV of every matrix: publish the tails (y_local[-1] of rows this rank
-        does not own: alpha*partial, its bias entry was zeroed), gather them, add the chain into the owner's
-        first row.  On the GPU: two tiny launches of libhispmv around ONE all_gather (a chain of ~30 torch
-        element ops would cost about half a step of the 20-matrix set).  prepared=True: `prepare` was called and
-        neither the y tensors nor the current stream changed since."""
+    def pack(self, mats, prepared: bool = False) -> None:
+        """First half of a step: the tails (y_local[-1] of rows this rank does not own: alpha*partial, its bias entry
+        was zeroed) -> self.send.  On the GPU one tiny launch of libhispmv."""
         torch = self.torch
-        if not self.ready:
-            self._setup(mats)
         if self.send.is_cuda:
             from ._lib import lib
-            if prepared:
-                stream = self._stream
-            else:
+            if not prepared:
                 self._device_tables(mats)
-                stream = torch.cuda.current_stream(self.device).cuda_stream
-            rc = lib.hispmv_boundary_pack(self._d_last.data_ptr(), self.tail_mask.data_ptr(), self.send.data_ptr(), self.n, stream)
+                self._stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = lib.hispmv_boundary_pack(self._d_last.data_ptr(), self.tail_mask.data_ptr(), self.send.data_ptr(), self.n, self._stream)
             if rc != 0:
                 raise RuntimeError(f"hispmv_boundary_pack failed ({rc})")
-            self._all_gather(self.recv, self.send)
-            rc = lib.hispmv_boundary_apply(self._d_first.data_ptr(), self.recv.data_ptr(), self._w.data_ptr(), self.n, self.world, stream)
-            if rc != 0:
-                raise RuntimeError(f"hispmv_boundary_apply failed ({rc})")
             return
         last = torch.stack([m["y"][-1] if ok else self.zero for m, ok in zip(mats, self.has_rows)])
         torch.mul(last, self.tail_mask, out=self.send)
-        self._all_gather(self.recv, self.send)
+
+    def apply(self, mats) -> None:
+        """Second half: self.recv (every rank's tails) -> the chain of this rank's first rows, added in rank order."""
+        if self.send.is_cuda:
+            from ._lib import lib
+            rc = lib.hispmv_boundary_apply(self._d_first.data_ptr(), self.recv.data_ptr(), self._w.data_ptr(), self.n, self.world, self._stream)
+            if rc != 0:
+                raise RuntimeError(f"hispmv_boundary_apply failed ({rc})")
+            return
         if self.heads:
             incoming = (self.recv.view(self.world, self.n).t() * self.weights).sum(dim=1)
             for i in self.heads:
                 mats[i]["y"][0] += incoming[i]
+
+    def run(self, mats, alpha: float = 1.0, prepared: bool = False) -> None:
+        """After every rank's local SpMV of every matrix: publish the tails, gather them, add the chain into the
+        owner's first row.  On the GPU: two tiny launches of libhispmv around ONE all_gather (a chain of ~30 torch
+        element ops would cost about half a step of the 20-matrix set).  prepared=True: `prepare` was called and
+        neither the y tensors nor the current stream changed since.  (`alpha` is already inside the tails.)"""
+        if not self.ready:
+            self._setup(mats)
+        self.pack(mats, prepared)
+        self._all_gather(self.recv, self.send)
+        self.apply(mats)
+
+
+class LoopbackWorld:
+    """`world` virtual ranks in ONE process: every rank keeps its own list of matrices (handles, vectors, Shard) and
+    its own BoundaryExchange; a step is `local_step(rank)` for every rank, then pack on every rank, the all_gather as a
+    concatenation of the send buffers, then apply on every rank -- the same two kernels and the same weights as the
+    process-per-GPU path, without a process group.  For checking the sharded path at world sizes a one-GPU box cannot
+    host as processes (tests/test_gpu_dist_full.py: world 8)."""
+
+    def __init__(self, per_rank_mats, device):
+        import torch
+        self.torch = torch
+        self.world = len(per_rank_mats)
+        self.mats = per_rank_mats
+        n = len(per_rank_mats[0])
+        self.ex = [BoundaryExchange(n, device, world=self.world, rank=r) for r in range(self.world)]
+        flags = [e.local_flags(m) for e, m in zip(self.ex, per_rank_mats)]
+        allf = np.stack(flags)
+        for e, m, f in zip(self.ex, per_rank_mats, flags):
+            e.finish_setup(m, f, allf)
+
+    def exchange(self) -> None:
+        for e, m in zip(self.ex, self.mats):
+            e.pack(m)
+        allsend = self.torch.cat([e.send for e in self.ex])
+        for e, m in zip(self.ex, self.mats):
+            e.recv.copy_(allsend)
+            e.apply(m)

@@ -34,12 +34,16 @@ class Prepared:
     tts: dict = None                  # the transposed tile stream (prep_from_coo(..., tts=True)): arrays + counts
 
 
-def _collect_tts(p, target, small: bool = False) -> dict:
+def _collect_tts(p, target, geometry: int = 0):
+    """geometry: 0 standard (8 K-row tiles), 1 small, "tall" = the list of the tall geometry's column parts (codes 2 + q)."""
     if isinstance(target, tuple):
-        target, small = target
+        target, geometry = target
+    if geometry in ("tall", "paired"):
+        return [_collect_tts(p, target, (2 if geometry == "tall" else 4) + q) for q in range(2)]
+    geometry = int(geometry)
     cnt = (C.c_int64 * 8)()
     lpg = C.c_double()
-    if lib.hispmv_prep_build_tts(p, int(target), int(bool(small)), cnt, C.byref(lpg)) != HISPMV_OK:
+    if lib.hispmv_prep_build_tts(p, int(target), geometry, cnt, C.byref(lpg)) != HISPMV_OK:
         raise ValueError(lib.hispmv_prep_last_error().decode())
     tiles, blocks, slices, chunks, fillers, pads, max_rows, max_slots = (int(v) for v in cnt)
 
@@ -52,7 +56,7 @@ def _collect_tts(p, target, small: bool = False) -> dict:
         return a.reshape(shape) if shape else a
     pc = (C.c_int64 * 2)()
     lib.hispmv_prep_tts_pieces(p, pc)
-    return dict(n_tiles=tiles, n_blocks=blocks, n_slices=slices, n_chunks=chunks, fillers=fillers, pad_words=pads, max_rows=max_rows,
+    return dict(zero_fill=geometry >= 2, n_tiles=tiles, n_blocks=blocks, n_slices=slices, n_chunks=chunks, fillers=fillers, pad_words=pads, max_rows=max_rows,
                 max_slots=max_slots, lines_per_gather=float(lpg.value), n_carry=int(pc[1]), fix=arr(6, int(pc[0]) * 4, np.int32, (-1, 4)),
                 words=arr(0, slices * 2048, np.uint32, (-1, 2, 1024)), col_base=arr(1, slices, np.int32), flags=arr(2, chunks * 64, np.uint16, (-1, 64)),
                 chunk_info=arr(3, chunks * 2, np.int32, (-1, 2)), tiles=arr(4, tiles * 4, np.int32, (-1, 4)), blocks=arr(5, blocks * 8, np.int32, (-1, 8)))
@@ -92,7 +96,8 @@ def _collect(p, tts=None) -> Prepared:
 
 def prep_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int, tts=None) -> Prepared:
     """tts: None, or the target elements per row tile of the transposed tile stream to pack as well (0 = loader's choice),
-    or (target, small_geometry) -- see hispmv_prep_build_tts."""
+    or (target, geometry) with geometry 0 standard / 1 small / "tall" (Prepared.tts is then the list of the two column
+    parts) -- see hispmv_prep_build_tts."""
     r = np.ascontiguousarray(coo_rows, dtype=np.int32)
     c = np.ascontiguousarray(coo_cols, dtype=np.int32)
     v = np.ascontiguousarray(coo_values, dtype=np.float32)

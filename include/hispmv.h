@@ -213,7 +213,11 @@ int64_t hispmv_free_failures(void);
  * before, chain_len} per chunk), 4 tiles ({row0, n_rows, block_begin, n_blocks}; row0 < 0: carry tile), 5 blocks (8 x int32: slice_begin,
  * n_slices, chunk_begin, n_chunks, n_slots, 0, 0, 0).  target_tile_elems 0 = the loader's choice; small_geometry: 0 = tiles of
  * <= 8192 rows and blocks of <= 28 K slots (one workgroup per CU), 1 = <= 4096 rows / 13 K slots (two per CU: what the
- * loader takes when a gather of the tall geometry touches <= 8 lines; hispmv_matrix_info.group_slices = 28 or 13). */
+ * loader takes when a gather of the tall geometry touches <= 8 lines; hispmv_matrix_info.group_slices = 28 or 13), 2 + q =
+ * column part q (0 or 1) of the TALL geometry as the loader builds it for 256 CUs: the matrix cut at the column that halves
+ * its elements, each half packed into tiles of <= 16384 rows and blocks of <= 23 K slots in which rows absent from a block
+ * own a slot but no word (hispmv_matrix_info.group_slices = 23, col_tiles = 2: part 0 gives alpha*A_0*x + beta*bias, part 1
+ * the partial vector alpha*A_1*x that the merge launch adds). */
 int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int small_geometry, int64_t counts[8], double* lines_per_gather);
 const void* hispmv_prep_tts_array(const hispmv_prep* p, int which);
 /* Rows longer than two tiles are cut into pieces, each a tile of its own; all but a row's last piece are carry tiles

@@ -72,7 +72,7 @@ def _load():
     lib.refpack_emulate.argtypes = [_p, _p, _p, C.c_float, C.c_float, _p]
     lib.emu_spmv.argtypes = [_p, _p, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int32, C.c_int]
     lib.emu_gemv.argtypes = [_p, C.c_int32, C.c_int32, _p, _p, C.c_float, C.c_float, _p]
-    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p]
+    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int]
     return lib
 
 
@@ -301,15 +301,22 @@ def emu_spmv(words, hdr, fix, x, bias, alpha, beta, rows, mode=0):
     return y
 
 
-def emu_tts(tts: dict, x, bias, alpha, beta, rows):
-    """CPU model of the transposed-tile-stream kernel on the product's own packed arrays (hispmv_amd.prep: Prepared.tts)."""
+def emu_tts(tts, x, bias, alpha, beta, rows):
+    """CPU model of the transposed-tile-stream kernel on the product's own packed arrays (hispmv_amd.prep: Prepared.tts).
+    A list of dicts = the column parts of the tall geometry: part 0 gives alpha*A_0*x + beta*bias, part t > 0 the partial
+    vector alpha*A_t*x, added in part order (spmv_merge_multi_kernel: y = (y + part_1) + ...)."""
+    if isinstance(tts, (list, tuple)):
+        y = emu_tts(tts[0], x, bias, alpha, beta, rows)
+        for part in tts[1:]:
+            y = y + emu_tts(part, x, bias, alpha, 0.0, rows)
+        return y
     w, cb, fl, ci = _c(tts["words"], np.uint32), _c(tts["col_base"], np.int32), _c(tts["flags"], np.uint16), _c(tts["chunk_info"], np.int32)
     ti, bl = _c(tts["tiles"], np.int32), _c(tts["blocks"], np.int32)
     xx, bb = _c(x, np.float32), _c(bias, np.float32)
     y = np.zeros(rows, dtype=np.float32)
     fx = _c(tts.get("fix", np.zeros((0, 4), np.int32)), np.int32)
     lib.emu_tts(_ptr(w), _ptr(cb), _ptr(fl), _ptr(ci), _ptr(ti), _ptr(bl), tts["n_tiles"], _ptr(fx), fx.shape[0], int(tts.get("n_carry", 0)),
-                _ptr(xx), _ptr(bb), alpha, beta, _ptr(y))
+                _ptr(xx), _ptr(bb), alpha, beta, _ptr(y), int(bool(tts.get("zero_fill", False))))
     return y
 
 

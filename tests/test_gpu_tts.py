@@ -37,12 +37,19 @@ def make(case, rng):
     return rows, cols, r.astype(np.int32), c.astype(np.int32), v
 
 
-@pytest.mark.parametrize("case", ["uniform_short_rows", "empty_and_heavy_rows", "wide_columns_few_rows", "banded_jitter", "duplicates"])
-def test_tile_stream_matches_its_model_and_the_fp64_truth(case, monkeypatch):
+CASES = [(c, "standard") for c in ("uniform_short_rows", "empty_and_heavy_rows", "wide_columns_few_rows", "banded_jitter", "duplicates")] + \
+        [(c, g) for g in ("tall", "paired") for c in ("uniform_short_rows", "empty_and_heavy_rows", "duplicates")]
+
+
+@pytest.mark.parametrize("case,geometry", CASES)
+def test_tile_stream_matches_its_model_and_the_fp64_truth(case, geometry, monkeypatch):
+    """geometry "tall": two column parts of 16 K-row tiles whose absent rows have no stream word (zero-filled staging),
+    part 1 through a partial vector and the merge launch, both parts pinned to XCD subsets in one grid."""
     import pyhispmv
     import torch
     from hispmv_amd.prep import prep_from_coo
     monkeypatch.setenv("HISPMV_FORMAT", "tts")
+    monkeypatch.setenv("HISPMV_TTS_GEOMETRY", geometry)
     rng = np.random.default_rng(abs(hash(case)) % 997)
     rows, cols, r, c, v = make(case, rng)
     x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
@@ -51,9 +58,11 @@ def test_tile_stream_matches_its_model_and_the_fp64_truth(case, monkeypatch):
     idx = h.create_sparse_handle(r, c, v, rows, cols)
     h.load_matrices()
     info = h.matrix_info(idx)
-    assert info["format"] == 1 and info["group_slices"] in (13, 28)
-    assert info["n_split_rows"] == (2 if case == "empty_and_heavy_rows" else 0)      # rows cut into pieces (carry tiles + fix-up)
-    P = prep_from_coo(r, c, v, rows, cols, tts=(0, info["group_slices"] == 13))     # the geometry the loader chose
+    assert info["format"] == 1 and info["group_slices"] == {"standard": 28, "tall": 23, "paired": 11}[geometry]
+    assert info["col_tiles"] == (1 if geometry == "standard" else 2)
+    if geometry == "standard":
+        assert info["n_split_rows"] == (2 if case == "empty_and_heavy_rows" else 0)      # rows cut into pieces (carry tiles + fix-up)
+    P = prep_from_coo(r, c, v, rows, cols, tts=(0, {13: 1, 28: 0, 23: "tall", 11: "paired"}[info["group_slices"]]))     # the geometry the loader chose
     rp = P.row_ptr.astype(np.int32)
     h.select_matrix(idx)
     for alpha, beta in ((ALPHA, BETA), (ALPHA_HOST, BETA_HOST), (1.0, 0.0), (-1.5, 0.5)):
