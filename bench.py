@@ -64,6 +64,8 @@ def parse_args():
                     "banded matrices added to the strong-scaling set, e.g. 2,4,8 (SURVEY.md 8d C5); generated rank-locally")
     ap.add_argument("--matrices", type=str, default="", help="comma-separated subset of the set (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed steps before the warm-up (clock ramp; 0 = none)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the fp64 self-check of one step's y (outside the timed region)")
     ap.add_argument("--no-extras", action="store_true", help="skip the standin_uniform and strong_scaling sub-measurements")
     ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds of timed CPU work per implementation and thread count")
     ap.add_argument("--per-matrix-reps", type=int, default=10)
@@ -271,7 +273,10 @@ class Runner:
             if m.get("dense") is not None:
                 m["idx"] = fpga.create_dense_handle(m["dense"].reshape(-1), m["rows"], m["cols"])
             elif "path" in m:
-                m["idx"] = fpga.create_sparse_handle_from_mtx(m["path"], 0)
+                # flavour 1 = the cpu/ driver's reader (readMatrixCSC + convertCSCtoCSR, cpu/src/helper_functions.cpp:91-241): the
+                # index-parity target of north_star and the loader whose restatement is pinned bit-exact by the reference
+                # itself (oracle/_ref); the common/ flavour (0) is parity-unpinned
+                m["idx"] = fpga.create_sparse_handle_from_mtx(m["path"], 1)
             else:
                 m["idx"] = fpga.create_sparse_handle_from_csr(m["rp"], m["ci"], m["va"], m["rows"], m["cols"])
             assert m["idx"] >= 0, f"{m['name']}: arena full"
@@ -312,6 +317,84 @@ class Runner:
             dist.barrier()
         self.torch.cuda.synchronize()
 
+    def preheat(self, step, seconds=0.3, max_steps=4000):
+        """Untimed clock ramp: the chip reaches its steady clocks only after ~15 ms of load (the set's step measured 0.315
+        ms in 20 steps behind 3 warm-up steps, 0.296-0.300 behind 100-200), so the measurement must not depend on the
+        caller's --warmup.  Steps are issued for `seconds` of wall time (bounded by max_steps), then the device drains;
+        reported as preheat_ms, outside every timed region."""
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds and n < max_steps:
+            for _ in range(20):
+                step()
+            n += 20
+            self.torch.cuda.synchronize()
+        self.fence()
+        return (time.perf_counter() - t0) * 1e3
+
+    def verify(self, mats, step):
+        """One step outside the timed region, every rank's y checked against a host fp64 product of ITS shard (scipy CSR
+        in fp64 -- not the oracle: bench.py touches oracle/ only in the cpu_baseline leg): backward error
+        max_i |y_i - y64_i| / (|alpha| sum_j |a_ij x_j| + |beta b_i|) over the rank's rows.  The first row of a shard whose
+        head is open also needs the tails of the ranks before it: they are gathered (fp64, host) over the process group
+        with the chain rule of hispmv_amd.dist.chain_weights.  -> (worst error over ranks, rows checked over ranks)."""
+        import scipy.sparse as sp
+        torch = self.torch
+        step()
+        self.fence()
+        worst, n_rows, skipped = 0.0, 0, 0
+        tails = []                                   # per matrix: (head_open, tail_open, single_row, tail value, tail magnitude)
+        exp_heads = []
+        for m in mats:
+            y = m["y"].cpu().numpy().astype(np.float64)
+            x = m["x"].cpu().numpy().astype(np.float64)
+            b = m["b"].cpu().numpy().astype(np.float64)
+            if m.get("dense") is not None:
+                W = m["dense"].astype(np.float64)
+                p, a = W @ x, np.abs(W) @ np.abs(x)
+            elif "rp" in m:
+                A = sp.csr_matrix((np.asarray(m["va"], np.float64), np.asarray(m["ci"]), np.asarray(m["rp"])), shape=(m["rows"], m["cols"]))
+                p = A @ x
+                A.data = np.abs(A.data)
+                a = A @ np.abs(x)
+            else:
+                skipped += 1                        # a real .mtx file loaded by the library: no host CSR to check against
+                tails.append((0, 0, 0, 0.0, 0.0)); exp_heads.append(None)
+                continue
+            y64 = ALPHA * p + BETA * b
+            mag = np.abs(ALPHA) * a + np.abs(BETA * b)
+            sh = m.get("shard")
+            lo, hi = 0, m["rows"]
+            if sh is not None and sh.head_open:
+                lo = 1
+            tails.append((int(bool(sh and sh.head_open)), int(bool(sh and sh.tail_open)), int(bool(sh and sh.n_rows == 1)),
+                          float(y64[-1]) if m["rows"] else 0.0, float(mag[-1]) if m["rows"] else 0.0))
+            exp_heads.append((float(y64[0]), float(mag[0]), float(y[0])) if (sh is not None and sh.head_open) else None)
+            if hi > lo:
+                err = np.abs(y[lo:hi] - y64[lo:hi]) / np.maximum(mag[lo:hi], 1e-300)
+                worst = max(worst, float(err.max()))
+                n_rows += hi - lo
+        if self.dist_on:
+            import torch.distributed as dist
+            from hispmv_amd.dist import chain_weights
+            allt = [None] * dist.get_world_size()
+            dist.all_gather_object(allt, tails)
+            rank = dist.get_rank()
+            for i, eh in enumerate(exp_heads):
+                if eh is None:
+                    continue
+                flags = np.array([[allt[r][i][0], allt[r][i][1], allt[r][i][2]] for r in range(len(allt))], np.float32)
+                w = chain_weights(flags, rank)
+                y0 = eh[0] + sum(w[r] * allt[r][i][3] for r in range(len(allt)))
+                m0 = eh[1] + sum(w[r] * allt[r][i][4] for r in range(len(allt)))
+                worst = max(worst, abs(eh[2] - y0) / max(m0, 1e-300))
+                n_rows += 1
+            tt = torch.tensor([worst, float(n_rows), float(skipped)], dtype=torch.float64, device=self.dev)
+            mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            worst, n_rows, skipped = float(mx[0]), int(sm[1]), int(sm[2])
+        return worst, n_rows, skipped
+
     def time_steps(self, step, steps, warmup):
         """EXACTLY `steps` steps between two fences (barrier + device synchronise), HIP events on the launch stream;
         -> (wall seconds, device seconds), max over ranks."""
@@ -338,9 +421,14 @@ class Runner:
 
 
 def latest_traffic(n_launches):
-    """HBM bytes per launch from the newest committed PMC summary (tools/profile_round.sh: FETCH_SIZE x2 + WRITE_SIZE in
-    separate passes, MI355X_MICROARCH.md "HBM")."""
-    cands = sorted((ROOT / "profiles").glob("*_traffic.json"), key=lambda q: q.stat().st_mtime)
+    """HBM bytes per launch from the committed PMC summary of the latest ROUND (tools/profile_round.sh: FETCH_SIZE x2 +
+    WRITE_SIZE in separate passes, MI355X_MICROARCH.md "HBM"): profiles/r<N>_traffic.json with the largest N -- chosen by
+    the round tag in the file name, never by modification time (arbitrary after a fresh checkout or push)."""
+    import re
+    def round_of(q):
+        m = re.match(r"r(\d+)_traffic\.json$", q.name)
+        return int(m.group(1)) if m else -1
+    cands = sorted((q for q in (ROOT / "profiles").glob("r*_traffic.json") if round_of(q) >= 0), key=round_of)
     for c in reversed(cands):
         try:
             tj = json.loads(c.read_text())
@@ -460,7 +548,11 @@ def main():
             if exch is not None:
                 exch.run(mats, ALPHA, prepared=True)
 
+    preheat_ms = R.preheat(step, args.preheat)
     t_wall, t_dev = R.time_steps(step, args.steps, args.warmup)
+    # self-check (outside the timed region): one more step, every rank's y against a host fp64 product of its shard
+    y_err, y_rows, y_skipped = (R.verify(mats, step) if not args.no_verify else (None, 0, len(mats)))
+    y_checked = (y_err is not None) and y_err < 1e-5 and y_rows > 0
 
     def alg_bytes(m):
         if m.get("dense") is not None:
@@ -582,9 +674,20 @@ def main():
                      "powerlaw": "BASELINE.json configs[2]: R-MAT scale 20 (ef 16, duplicates kept) + Zipf(1.2) row lengths at soc-Pokec's shape",
                      "dense": "dense overlay GeMV, sizes of cpu/run_gemv.sh:9-13 (512..8192 square)",
                      "model": "BASELINE.json configs[3]: apps/model_test.py layers 4096->8192 dense, 8192->8192 d=0.1, 8192->1024 d=0.25, one launch per layer"}
-        dominant = {"set": "spmv_slices_multi_kernel (matrices of one workgroup size share a grid; + one fix-up and one merge launch per step)"
-                           if args.launch == "batch" else "spmv_slices_kernel (+ carry fix-up launches)",
-                    "powerlaw": "spmv_slices_multi_kernel", "dense": "gemv_rows_kernel", "model": "gemv_rows_kernel + spmv_slices_multi_kernel"}[args.workload]
+        # every kernel with >= 10 % of a step's kernel time (profiles/r3_kernel_stats_single_stream.csv)
+        dominant = {"set": "spmv_slices_multi_kernel (two grids per step: the 1024-thread and the 256-thread slice streams) + "
+                           "spmv_tts_multi_kernel (the tile streams: soc-Pokec, nxp1, analytics, boyd2, language); + one fix-up and one merge launch per step"
+                           if args.launch == "batch" else "spmv_slices_kernel / spmv_tts_kernel (+ carry fix-up launches)",
+                    "powerlaw": "spmv_tts_multi_kernel (both matrices are tile streams; + one fix-up launch for the rows cut into pieces)",
+                    "dense": "gemv_rows_multi_kernel",
+                    "model": "gemv_rows_multi_kernel + spmv_slices_multi_kernel + spmv_tts_multi_kernel (one layer each)"}[args.workload]
+        classes = {}
+        for m in mats:
+            info = fpga.matrix_info(m["idx"])
+            key = ("gemv_rows_multi_kernel" if info["is_dense"] else
+                   f"spmv_tts_multi_kernel/{info['block_threads']}t" if info["format"] == 1 else f"spmv_slices_multi_kernel/{info['block_threads']}t")
+            cl = classes.setdefault(key, {"matrices": [], "algorithmic_bytes_per_launch": 0, "flops_per_launch": 0})
+            cl["matrices"].append(m["name"]); cl["algorithmic_bytes_per_launch"] += int(alg_bytes(m)); cl["flops_per_launch"] += int(flops_of(m))
         out = {
             "metric": {"set": "SpMV GFLOP/s, SuiteSparse set (20 matrices), fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
                        "powerlaw": "SpMV GFLOP/s, power-law matrices, fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
@@ -612,6 +715,12 @@ def main():
                          "avg_launch_us": round(t_dev / launches * 1e6, 3),
                          "note": "achieved = sum over the workload of the algorithmic bytes (SpMV: 8*nnz+16*rows+4, GeMV: 4*rows*cols+4*cols+8*rows) "
                                  "/ HIP-event time of the timed region on the launch stream"},
+            "y_checked": bool(y_checked),
+            "y_check": {"max_backward_error": y_err, "rows_checked": y_rows, "matrices_without_host_csr": y_skipped, "gate": 1e-5,
+                        "how": "one step after the timed region; every rank: host fp64 product (scipy CSR) of its shard, cut rows with the "
+                               "gathered fp64 tails of the ranks before it"},
+            "preheat_ms": round(preheat_ms, 1),
+            "launch_classes": classes,
             "host": {"gen_s": round(t_gen, 1), "prep_upload_s": round(t_prep, 1)},
         }
         out.update(extras)
@@ -626,6 +735,8 @@ def main():
     fpga.close()
     if dist_on:
         dist.destroy_process_group()
+    if not args.no_verify and not y_checked:
+        sys.exit(f"bench.py: the y self-check failed (max backward error {y_err}, rows checked {y_rows})")
 
 
 if __name__ == "__main__":

@@ -80,6 +80,7 @@ struct hispmv_ctx {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int batch_streams = 2;
+    int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first
     bool batch_graphs = true;    // HISPMV_BATCH_GRAPH=0: no HIP graph replay of batch calls
     // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
     // the three model_test layers: 49.9 us on one stream, 63.1 on two; the 20-matrix set: 353 -> 344 us with two)
@@ -120,10 +121,12 @@ struct hispmv_ctx {
         int64_t stream_bytes = 0;     // 8 B per entry of the call's sparse matrices: decides whether side streams pay
         // HISPMV_BATCH_GRAPH=1 (experiment): the launches of a two-stream call captured once into a HIP graph and replayed
         hipGraphExec_t graph = nullptr;
+        hipGraph_t graph_src = nullptr;      // the captured graph `graph` was instantiated from (kept: its node handles patch alpha)
         float graph_alpha = 0.0f;
         int runs = 0;
     };
     std::vector<BatchPlan> batch_plans;
+    int64_t graph_instantiations = 0, graph_alpha_updates = 0;     // hispmv_batch_graph_stats
     // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
     // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
     // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.
@@ -182,6 +185,7 @@ template <class T> void host_free(T*& p) {
 void free_batch_plans(hispmv_ctx* c) {
     for (auto& p : c->batch_plans) {
         if (p.graph) { (void)hipGraphExecDestroy(p.graph); p.graph = nullptr; }
+        if (p.graph_src) { (void)hipGraphDestroy(p.graph_src); p.graph_src = nullptr; }
         for (auto& l : p.launches) dev_free(l.d_table);
     }
     c->batch_plans.clear();
@@ -468,7 +472,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
                       float* const* d_y, float alpha, float beta, hipStream_t s);
 
 int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
-                  float alpha, float beta, hipStream_t s) {
+                  float alpha, float beta, hipStream_t s, bool fixup_only = false) {
     if (!m.dense && m.parts.size() > 1 && m.index >= 0) {
         // column tiles: all of them in ONE grid (+ one fix-up, one merge launch) through the batch machinery -- launched
         // one after the other each tile had the chip to itself for half the work (mouse_gene 48 -> 40 us)
@@ -487,8 +491,8 @@ int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bia
     }
     for (size_t t = 0; t < m.parts.size(); ++t) {
         // column tile 0 computes alpha*A_0*x + beta*bias into y; tile t > 0 writes alpha*A_t*x into its partial vector
-        hipError_t e = (t == 0) ? launch_spmv(m.parts[t].dev, d_x, d_bias, d_y, alpha, beta, s)
-                                : launch_spmv(m.parts[t].dev, d_x, nullptr, m.d_ypart + (t - 1) * (size_t)kMaxBatch * m.rows, alpha, 0.0f, s);
+        hipError_t e = (t == 0) ? launch_spmv(m.parts[t].dev, d_x, d_bias, d_y, alpha, beta, s, fixup_only)
+                                : launch_spmv(m.parts[t].dev, d_x, nullptr, m.d_ypart + (t - 1) * (size_t)kMaxBatch * m.rows, alpha, 0.0f, s, fixup_only);
         if (e != hipSuccess) return hip_fail(c, e, "launch_spmv");
     }
     if (m.parts.size() > 1) {
@@ -501,8 +505,9 @@ int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bia
 // `vecs` vectors with a shared bias (FpgaHandle::linear): the reference relaunches its kernel per vector
 // (fpga_handle.cpp:366-379); here up to 8 (dense) / 4 (sparse) vectors share one pass over the matrix when the plan allows.
 int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d_x, const float* d_bias, float* d_y,
-                          float alpha, float beta, hipStream_t s) {
-    if (vecs == 1) return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, s);
+                          float alpha, float beta, hipStream_t s, bool fixup_only) {
+    // (`linear` always takes the fix-up carry variant: one vector or many, every vector gets the same bits)
+    if (vecs == 1) return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, s, fixup_only);
     if (m.dense) {
         hipError_t e = launch_gemv_batched(m.d_dense, m.rows, m.cols, vecs, d_x, d_bias, d_y, alpha, beta, s);
         if (e != hipSuccess) return hip_fail(c, e, "launch_gemv_batched");
@@ -522,7 +527,7 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
         const float* xk = d_x + k * m.cols;
         float* yk = d_y + k * m.rows;
         if (nv < 2) {
-            int rc = launch_matrix(c, m, xk, d_bias, yk, alpha, beta, s);
+            int rc = launch_matrix(c, m, xk, d_bias, yk, alpha, beta, s, true);
             if (rc != HISPMV_OK) return rc;
             k += 1;
             continue;
@@ -604,6 +609,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     if (const char* env = std::getenv("HISPMV_BATCH_GRAPH")) c->batch_graphs = std::atoi(env) != 0;
+    if (const char* env = std::getenv("HISPMV_BATCH_ORDER")) c->batch_order = !std::strcmp(env, "small_first") ? 1 : 0;
     if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) { c->batch_streams = std::max(1, std::min(3, std::atoi(env))); c->batch_streams_min_bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate(side)");
@@ -870,7 +876,7 @@ HISPMV_API int hispmv_select_matrix(hispmv_ctx* c, uint32_t idx) {
 }
 
 static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t num_vecs, const float* bias,
-                            float* y, float alpha, float beta) {
+                            float* y, float alpha, float beta, bool is_linear) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
     // device side: [x (num_vecs * cols) | bias (rows)] in one block, y in another
@@ -897,7 +903,7 @@ static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t nu
         if (beta != 0.0f) HIP_TRY(c, hipMemcpyAsync(d_bias, bias, bb, hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if ((rc = launch_matrix_vectors(c, m, num_vecs, d_x, d_bias, c->d_y, alpha, beta, c->stream)) != HISPMV_OK) return rc;
+    if ((rc = launch_matrix_vectors(c, m, num_vecs, d_x, d_bias, c->d_y, alpha, beta, c->stream, is_linear)) != HISPMV_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     float* const h_y = staged ? c->h_stage + nx + nb : y;
     HIP_TRY(c, hipMemcpyAsync(h_y, c->d_y, by, hipMemcpyDeviceToHost, c->stream));
@@ -914,7 +920,7 @@ HISPMV_API int hispmv_run_kernel(hispmv_ctx* c, const float* x, const float* bia
     Matrix& m = *c->mats[c->selected];
     if (!m.loaded) return fail(c, HISPMV_ESTATE, "run_kernel called before load_matrices");
     if (!x || !y || (beta != 0.0f && !bias)) return fail(c, HISPMV_EINVAL, "NULL vector");
-    return run_host_vectors(c, m, x, 1, bias, y, alpha, beta);
+    return run_host_vectors(c, m, x, 1, bias, y, alpha, beta, false);
 }
 
 HISPMV_API int hispmv_linear(hispmv_ctx* c, int idx, const float* x, int64_t x_len, const float* bias, float* y_out) {
@@ -926,7 +932,7 @@ HISPMV_API int hispmv_linear(hispmv_ctx* c, int idx, const float* x, int64_t x_l
     if (!x || !bias || !y_out) return fail(c, HISPMV_EINVAL, "NULL vector");
     const int64_t num_vecs = x_len / m.cols;   // fpga_handle.cpp:336
     if (num_vecs <= 0) return fail(c, HISPMV_EINVAL, "x shorter than one input vector");
-    return run_host_vectors(c, m, x, num_vecs, bias, y_out, 1.0f, 1.0f);   // alpha = beta = 1, :351-352
+    return run_host_vectors(c, m, x, num_vecs, bias, y_out, 1.0f, 1.0f, true);   // alpha = beta = 1, :351-352
 }
 
 HISPMV_API int hispmv_spmv_device(hispmv_ctx* c, int idx, const float* d_x, const float* d_bias, float* d_y,
@@ -1046,6 +1052,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         if (a.threads != b.threads) return a.threads > b.threads;
         return a.slices > b.slices;
     });
+    const size_t first_slice_launch = plan.launches.size();
     for (const Item& it : items) for (const Ref& r : it.refs) refs.push_back(r);
     auto upload_table = [&](hispmv_ctx::BatchLaunch& l, const void* host, size_t bytes) -> int {
         HIP_TRY(c, hipMalloc(&l.d_table, bytes));
@@ -1075,6 +1082,22 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         }
         plan.launches.push_back(std::move(l));
         if ((rc = upload_table(plan.launches.back(), entries.data(), entries.size() * sizeof(MultiEntry))) != HISPMV_OK) return rc;
+    }
+    // Launch order = stream assignment (main launch k goes to lane k mod lanes, hispmv_spmv_device_batch).  HISPMV_BATCH_ORDER=
+    // small_first: the slice grids of SMALL workgroups first (256 threads, then 512, 1024), ahead of the tile streams: a
+    // 256-thread workgroup (4 wavefronts, a few KiB of LDS) fits on a CU NEXT TO a 1024-thread slice workgroup (91 VGPRs: five
+    // wavefronts per SIMD; windows of <= 115 KiB), so launched together the two grids share CUs -- the small matrices' L2
+    // gathers ride under the HBM-bound stream of the large ones -- while a tile (145 KiB, 16 x 126 VGPRs) shares with nobody.
+    if (c->batch_order == 1) {
+        std::vector<hispmv_ctx::BatchLaunch> slices(std::make_move_iterator(plan.launches.begin() + (long)first_slice_launch),
+                                                    std::make_move_iterator(plan.launches.end()));
+        plan.launches.erase(plan.launches.begin() + (long)first_slice_launch, plan.launches.end());
+        std::reverse(slices.begin(), slices.end());
+        // small slice grids, then the large ones, then whatever was there before (dense, tile streams)
+        std::vector<hispmv_ctx::BatchLaunch> rest = std::move(plan.launches);
+        plan.launches.clear();
+        for (auto& l : slices) plan.launches.push_back(std::move(l));
+        for (auto& l : rest) plan.launches.push_back(std::move(l));
     }
     std::vector<Ref> fixrefs = refs;                            // + tile streams that cut long rows into pieces
     for (int i = 0; i < n; ++i) {
@@ -1209,10 +1232,19 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     // of the two streams become graph edges.  HISPMV_BATCH_GRAPH=0 switches it off; a stream that is being captured by the
     // caller, or a capture the runtime refuses, falls back to plain launches.
     if (c->batch_graphs && lanes > 1) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
-        if (plan->graph && plan->graph_alpha == alpha) {
+        auto drop_graph = [&]() {
+            if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
+            if (plan->graph_src) { (void)hipGraphDestroy(plan->graph_src); plan->graph_src = nullptr; }
+        };
+        if (plan->graph && plan->graph_alpha != alpha) {
+            // another alpha on the same call: patch the kernel nodes of the instantiated graph (no capture, no instantiation)
+            if (plan->graph_src && graph_set_alpha(plan->graph, plan->graph_src, alpha) == hipSuccess) { plan->graph_alpha = alpha; c->graph_alpha_updates++; }
+            else { (void)hipGetLastError(); drop_graph(); }
+        }
+        if (plan->graph) {
             if (hipGraphLaunch(plan->graph, s) == hipSuccess) return HISPMV_OK;
             (void)hipGetLastError();
-            (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr;
+            drop_graph();
         }
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (plan->runs >= 1 && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone &&
@@ -1221,14 +1253,15 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
             hipGraph_t g = nullptr;
             const hipError_t e_end = hipStreamEndCapture(s, &g);
             if (rc != HISPMV_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-            if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
+            drop_graph();
             hipError_t e = e_end;
             if (e == hipSuccess) e = hipGraphInstantiate(&plan->graph, g, nullptr, nullptr, 0);
-            if (g) (void)hipGraphDestroy(g);
+            if (e == hipSuccess) c->graph_instantiations++;
+            plan->graph_src = g;
             if (e == hipSuccess) e = hipGraphLaunch(plan->graph, s);
             if (e == hipSuccess) { plan->graph_alpha = alpha; return HISPMV_OK; }
             (void)hipGetLastError();
-            if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
+            drop_graph();
             c->batch_graphs = false;               // this runtime / stream does not take it: plain launches from here on
         } else {
             (void)hipGetLastError();
@@ -1254,6 +1287,13 @@ HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
 }
 
 HISPMV_API float hispmv_last_kernel_ms(hispmv_ctx* c) { return c ? c->last_ms : -1.0f; }
+
+HISPMV_API int hispmv_batch_graph_stats(hispmv_ctx* c, int64_t out[2]) {
+    if (!c || !out) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    out[0] = c->graph_instantiations; out[1] = c->graph_alpha_updates;
+    return HISPMV_OK;
+}
 
 HISPMV_API float hispmv_time_device(hispmv_ctx* c, int idx, const float* d_x, const float* d_bias, float* d_y,
                                     float alpha, float beta, int reps) {

@@ -102,7 +102,7 @@ hipError_t prepare_spmv_kernels();
 // y = alpha*A*x + beta*bias.  Two launches on `stream`: the slice kernel, then (if any row is
 // shared between slices) the carry fix-up.  Returns the first HIP error.
 hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, float* y,
-                       float alpha, float beta, hipStream_t stream);
+                       float alpha, float beta, hipStream_t stream, bool fixup_only = false);
 
 // Batched SpMV (linear with several vectors): how many vectors (4, 2 or 1 = use launch_spmv) one pass can take for
 // this matrix, and the launch: vector v is x + v*cols -> y + v*rows; bias_stride 0 (shared) or rows (per vector).
@@ -145,6 +145,9 @@ hipError_t launch_gemv_multi(const GemvEntry* entries, int n, const GemvEntry* d
 // `vecs` vectors (x + v*cols -> y + v*rows, shared bias), 8/4/2/1 per pass over W; per vector bitwise equal to launch_gemv.
 hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64_t vecs, const float* x, const float* bias,
                                float* y, float alpha, float beta, hipStream_t stream);
+
+// Patches alpha into every kernel node of an instantiated batch-call graph (`graph`: the captured graph it came from).
+hipError_t graph_set_alpha(hipGraphExec_t exec, hipGraph_t graph, float alpha);
 
 // Multi-GPU boundary rows (hispmv.h: hispmv_boundary_pack / hispmv_boundary_apply).
 hipError_t launch_boundary_pack(const float* const* last, const float* mask, float* send, int n, hipStream_t stream);

@@ -22,6 +22,7 @@
 #include "hispmv_kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace hispmv {
 
@@ -947,9 +948,15 @@ hipError_t prepare_spmv_kernels() {
     return hipSuccess;
 }
 
-hipError_t launch_spmv(SpmvDeviceMatrix& m, const float* x, const float* bias, float* y,
-                       float alpha, float beta, hipStream_t stream) {
+hipError_t launch_spmv(SpmvDeviceMatrix& m_in, const float* x, const float* bias, float* y,
+                       float alpha, float beta, hipStream_t stream, bool fixup_only) {
     (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
+    // fixup_only (FpgaHandle::linear): the carry hand-off through the fix-up launch even where a single launch would merge
+    // the cut rows in-kernel -- the summation order of the batched kernels, so that every vector of a `linear` call has
+    // the same bits whatever the number of vectors in the call
+    SpmvDeviceMatrix forced;
+    if (fixup_only && m_in.lookback) { forced = m_in; forced.lookback = false; }
+    SpmvDeviceMatrix& m = (fixup_only && m_in.lookback) ? forced : m_in;
     if (m.n_slices > 0) {
         if (m.n_groups <= 0 || m.n_groups > 0x7fffffffLL) return hipErrorInvalidValue;
         LookbackArgs lb{};
@@ -1516,6 +1523,43 @@ hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64
         else { launch_gemv_nv<1>(W, rows, cols, xk, bias, yk, alpha, beta, stream); k += 1; }
     }
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// A batch call replayed as a HIP graph (hispmv_abi.cpp) with another alpha: alpha is a by-value argument of every kernel of
+// the call, so the instantiated graph is patched in place -- hipGraphExecKernelNodeSetParams on each of its kernel nodes --
+// instead of being captured and instantiated again (a solver that changes alpha every step would pay an instantiation
+// per step).  `graph` is the captured graph the executable was instantiated from (its node handles address the
+// executable's nodes).  Any failure makes the caller fall back to a fresh capture.
+// ---------------------------------------------------------------------------
+hipError_t graph_set_alpha(hipGraphExec_t exec, hipGraph_t graph, float alpha) {
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+    if (e != hipSuccess) return e;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && (e = hipGraphGetNodes(graph, nodes.data(), &n)) != hipSuccess) return e;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType type;
+        if ((e = hipGraphNodeGetType(nodes[i], &type)) != hipSuccess) return e;
+        if (type != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams p{};
+        if ((e = hipGraphKernelNodeGetParams(nodes[i], &p)) != hipSuccess) return e;
+        int idx, n_args;
+        if (p.func == (void*)spmv_slices_multi_kernel || p.func == (void*)spmv_tts_multi_kernel || p.func == (void*)gemv_rows_multi_kernel ||
+            p.func == (void*)spmv_fixup_multi_kernel) { idx = 2; n_args = 3; }
+        else if (p.func == (void*)spmv_fixup_long_kernel) { idx = 4; n_args = 7; }
+        else if (p.func == (void*)spmv_merge_multi_kernel) continue;          // no alpha
+        else return hipErrorInvalidValue;                                      // a kernel this function does not know: do not guess
+        if (!p.kernelParams) return hipErrorInvalidValue;
+        void* args[8];
+        for (int k = 0; k < n_args; ++k) args[k] = p.kernelParams[k];
+        float a = alpha;
+        args[idx] = &a;
+        p.kernelParams = args;
+        p.extra = nullptr;
+        if ((e = hipGraphExecKernelNodeSetParams(exec, nodes[i], &p)) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------

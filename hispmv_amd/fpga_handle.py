@@ -201,3 +201,10 @@ class FpgaHandle:
 
     def last_kernel_ms(self) -> float:
         return float(lib.hispmv_last_kernel_ms(self._ctx))
+
+    def batch_graph_stats(self) -> dict:
+        """{"instantiations", "alpha_updates"} of the HIP-graph replay of spmv_device_batch (hispmv_batch_graph_stats)."""
+        import ctypes as C
+        out = (C.c_int64 * 2)()
+        self._check(lib.hispmv_batch_graph_stats(self._ctx, out))
+        return {"instantiations": int(out[0]), "alpha_updates": int(out[1])}

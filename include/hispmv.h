@@ -108,6 +108,11 @@ int hispmv_synchronize(hispmv_ctx* ctx);
  * measured with HIP events on the launch stream (milliseconds); negative if unavailable. */
 float hispmv_last_kernel_ms(hispmv_ctx* ctx);
 
+/* Diagnostics of the HIP-graph replay of hispmv_spmv_device_batch: out = {graphs instantiated, alpha patches applied to an
+ * instantiated graph}.  A call signature (handles, vectors, beta) is captured and instantiated ONCE; calls that differ only
+ * in alpha patch the graph's kernel nodes (hipGraphExecKernelNodeSetParams) instead of instantiating again. */
+int hispmv_batch_graph_stats(hispmv_ctx* ctx, int64_t out[2]);
+
 /* n independent SpMVs y_i = alpha*A_i*x_i + beta*bias_i on loaded handles idx[i] in as few launches as possible: the
  * workgroups of all matrices with the same workgroup size share ONE grid (plus one fix-up launch), so small matrices no
  * longer pay 6-20 us of launch latency each (no reference counterpart: the reference runs one matrix at a time,

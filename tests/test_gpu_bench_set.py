@@ -19,6 +19,8 @@ from conftest import ALPHA, BETA, TOL, ref_vectors
 pytestmark = pytest.mark.gpu
 
 HW = ("tests.xclbin", 0, 24, 1, 1, 2, 5, True, False, True)   # apps/general_test.py:10-19
+TIGHT = 1e-6        # backward error vs the fp64 accumulation: the measured envelope (profiles/r2_parity_report.json: worst 2.5e-7), 10x inside the 1e-5 gate
+MKL_BWD = 3e-6      # difference to mkl_sparse_s_mv in the same scale (measured worst 1.36e-6: MKL's own rounding adds to ours)
 REPORT = []
 
 
@@ -37,6 +39,7 @@ def check_y(name, y, rp, ci, va, cols, x, b, alpha, beta, mkl=True):
     bwd = float(np.max(err / mag))
     assert np.all(np.isfinite(y)), f"{name}: non-finite y"
     assert bwd < TOL, f"{name}: backward error {bwd:.3e}"
+    assert bwd < TIGHT, f"{name}: backward error {bwd:.3e} above the measured envelope (worst over rounds 2-3: 2.5e-7)"
     nz = np.abs(y64) > 0
     rel = np.zeros_like(err)
     rel[nz] = err[nz] / np.abs(y64[nz])
@@ -48,8 +51,18 @@ def check_y(name, y, rp, ci, va, cols, x, b, alpha, beta, mkl=True):
     if mkl and oracle.mkl_available():
         r = oracle.mkl_spmv(rp, ci, va, cols, x, b, alpha, beta, 1, 0)
         if r is not None:
-            d = float(np.max(np.abs(y.astype(np.float64) - r[2].astype(np.float64)) / mag))
-            assert d < 2 * TOL, f"{name}: differs from mkl_sparse_s_mv by {d:.3e} (backward scale)"
+            ym = r[2].astype(np.float64)
+            d = float(np.max(np.abs(y.astype(np.float64) - ym) / mag))
+            # two fp32 summations of different order against each other: each is within ~1e-6 of the fp64 value in this
+            # scale (worst measured difference over rounds 2-3: 1.36e-6)
+            assert d < MKL_BWD, f"{name}: differs from mkl_sparse_s_mv by {d:.3e} (backward scale)"
+            # ... and the literal north_star reading against the MKL path: |y - y_mkl| / |y_mkl| <= 1e-5 on rows whose terms
+            # do not cancel
+            wm = well & (np.abs(ym) > 0)
+            if wm.any():
+                rel_mkl = float(np.max(np.abs(y.astype(np.float64)[wm] - ym[wm]) / np.abs(ym[wm])))
+                assert rel_mkl < TOL, f"{name}: plain relative difference to mkl_sparse_s_mv {rel_mkl:.3e} on a row without cancellation"
+                out["rel_vs_mkl_well"] = rel_mkl
             pl, _, _ = oracle.precision_loss(r[2], y)      # the reference's own metric, cpu/src/main.cpp:99-132
             assert pl < 1e-5, f"{name}: precision loss vs MKL {pl:.3e}"
             out["vs_mkl"] = d
@@ -95,6 +108,27 @@ def run_set(torch, mats, label):
                 h.spmv_device_batch(batch, ALPHA, BETA, 0)          # back to the first alpha: captured once more, results checked below
                 h.synchronize()
                 torch.cuda.synchronize()
+        # a call signature is captured and instantiated at most once; another alpha patches the instantiated graph's kernel
+        # nodes (a solver that changes alpha every step must not pay an instantiation per step)
+        st = h.batch_graph_stats()
+        assert st["instantiations"] <= 1 and (st["instantiations"] == 0 or st["alpha_updates"] == 2), st
+        if st["instantiations"]:
+            big = max(mats, key=lambda q: len(q["va"]))
+            for k in range(6):
+                a_k = np.float32(0.3 + 0.25 * k)
+                h.spmv_device_batch(batch, a_k, BETA, 0)
+            h.synchronize()
+            torch.cuda.synchronize()
+            check_y(f'{label}:{big["name"]}:batch:alpha_sweep', big["dy"].cpu().numpy(), big["rp"], big["ci"], big["va"], big["cols"], big["x"], big["b"],
+                    float(a_k), BETA, mkl=False)
+            st2 = h.batch_graph_stats()
+            assert st2["instantiations"] == 1 and st2["alpha_updates"] == st["alpha_updates"] + 6, st2
+            for m in mats:
+                m["dy"].fill_(float("nan"))
+            torch.cuda.synchronize()
+            h.spmv_device_batch(batch, ALPHA, BETA, 0)
+            h.synchronize()
+            torch.cuda.synchronize()
         for m in mats:
             yb = m["dy"].cpu().numpy()
             info = h.matrix_info(m["idx"])
@@ -191,13 +225,10 @@ def test_model_test_layers_full_size(batch):
                 check_y(f"C4:layer{idx}:{kind}:b{batch}:v{k}", out[k * rows:(k + 1) * rows], rp, ci, va, cols,
                         x[k * cols:(k + 1) * cols], bias, 1.0, 1.0, mkl=(k == 0))
             if batch > 1:
-                # a batched pass gives every vector the bits of its single-vector run with the fix-up carry variant; a matrix
-                # whose single launch merges its cut rows in-kernel (look-back) may differ in the last bit of those rows
+                # `linear` takes the fix-up carry variant whatever the number of vectors (also where a single run_kernel launch
+                # merges its cut rows in-kernel): every vector of a call has the bits of its one-vector call
                 one = h.linear(idx, x[:cols], bias)
-                if kind == "dense" or not h.matrix_info(idx)["carry_lookback"]:
-                    assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
-                else:
-                    assert np.allclose(one, out[:rows], rtol=1e-5, atol=1e-5 * float(np.max(np.abs(one))))
+                assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
     finally:
         h.close()
 

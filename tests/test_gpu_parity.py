@@ -99,7 +99,7 @@ def test_golden_matrices_vs_mkl_and_emulator(name, golden, fpga):
     fpga.run_kernel(x, y0, y, ALPHA, BETA)
     y64, mag = oracle.spmv_f64(g["ref_row_ptr"], g["ref_col_idx"], g["ref_vals"], x, y0, ALPHA, BETA)
     assert bwd_err(y, y64, mag) < TOL
-    assert float(np.max(np.abs(y.astype(np.float64) - g["y_mkl"]) / mag)) < 2 * TOL     # vs the cpu/ MKL path
+    assert float(np.max(np.abs(y.astype(np.float64) - g["y_mkl"]) / mag)) < 3e-6        # vs the cpu/ MKL path (measured envelope: 1.4e-6)
     pl, mre, _ = oracle.precision_loss(g["y_mkl"], y)                                    # the reference's own metric
     assert pl < 1e-5
     # the CPU model of the wavefront performs the same fp32 operations in the same order

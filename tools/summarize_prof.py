@@ -58,6 +58,51 @@ if trace:
                 "un-profiled run (MI355X_MICROARCH.md, DVFS), bench.py's HIP-event time is the un-profiled figure.", ""]
 
 
+# Per-kernel roofline fraction from the SINGLE-STREAM trace (HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0: the launches of a
+# step run one after the other, so a kernel's duration is its own): algorithmic bytes of the matrices in the grid
+# (bench.py's "launch_classes", from the JSON line in the pass's log) / average duration / 8 TB/s.
+single = first("trace_single/**/*kernel_trace.csv")
+if single:
+    classes = {}
+    try:
+        for line in (src / "trace_single.log").read_text().splitlines():
+            if line.startswith("{") and "launch_classes" in line:
+                classes = json.loads(line)["launch_classes"]
+    except Exception:
+        pass
+    rows_k = [r for r in csv.DictReader(open(single)) if "hispmv::" in r["Kernel_Name"]]
+    # the timed steps are the last 30 of 230: keep the last 30 launches of every (kernel, workgroup size)
+    per = defaultdict(list)
+    for r in rows_k:
+        per[(r["Kernel_Name"].split("(")[0].replace("hispmv::", ""), int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    table = []
+    for (name, wg), d in sorted(per.items(), key=lambda kv: -sum(kv[1][-30:])):
+        tail = d[-30:]
+        avg = sum(tail) / len(tail)
+        key = f"{name}/{wg}t" if ("slices_multi" in name or "tts_multi" in name) else name
+        cl = classes.get(key, {})
+        ab = cl.get("algorithmic_bytes_per_launch")
+        table.append({"kernel": name, "workgroup": wg, "launches_averaged": len(tail), "avg_us": round(avg, 2), "min_us": round(min(tail), 2),
+                      "matrices": cl.get("matrices"), "algorithmic_bytes_per_launch": ab,
+                      "achieved_gbs": round(ab / avg / 1e3, 1) if ab else None, "frac_of_8TBs": round(ab / avg / 1e3 / 8000.0, 4) if ab else None})
+    with open(dst / f"{tag}_kernel_stats_single_stream.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "workgroup_threads", "launches_averaged", "avg_us", "min_us", "algorithmic_bytes_per_launch", "achieved_GBs", "frac_of_8TBs", "matrices"])
+        for t in table:
+            w.writerow([t["kernel"], t["workgroup"], t["launches_averaged"], t["avg_us"], t["min_us"], t["algorithmic_bytes_per_launch"], t["achieved_gbs"],
+                        t["frac_of_8TBs"], " ".join(t["matrices"] or [])])
+    (dst / f"{tag}_per_kernel_roofline.json").write_text(json.dumps({"method": "single-stream kernel trace (HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0), last 30 launches of every kernel; "
+                                                                      "algorithmic bytes per grid from bench.py launch_classes (8*nnz+16*rows+4 per matrix); peak 8 TB/s",
+                                                                      "kernels": table, "step_us_sum_of_kernels": round(sum(t["avg_us"] for t in table), 1)}, indent=1) + "\n")
+    out += ["## Per kernel, one stream (`HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0`, last 30 steps)", "",
+            "| kernel | workgroup | avg us | algorithmic MB per launch | GB/s | frac of 8 TB/s | matrices |", "|---|---:|---:|---:|---:|---:|---|"]
+    for t in table:
+        ab = t["algorithmic_bytes_per_launch"]
+        out.append(f"| `{t['kernel']}` | {t['workgroup']} | {t['avg_us']:.2f} | {ab / 1e6:.1f} | {t['achieved_gbs']} | {t['frac_of_8TBs']} | {' '.join(t['matrices'] or [])} |" if ab else
+                   f"| `{t['kernel']}` | {t['workgroup']} | {t['avg_us']:.2f} | – | – | – | (not counted as algorithmic) |")
+    out += ["", f"Sum of the kernel averages: {sum(t['avg_us'] for t in table):.1f} us per step on one stream.", ""]
+
+
 def pmc(kind, counter):
     f = first(f"{kind}/**/*counter_collection.csv")
     if not f:
