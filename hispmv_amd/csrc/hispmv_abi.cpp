@@ -63,6 +63,9 @@ struct Matrix {
     // column tiles t > 0 write alpha*A_t*x here (tile t, vector v of a batched pass: d_ypart + ((t-1)*kMaxBatch + v)*rows);
     // a merge pass adds them to y after the cut rows of every tile are fixed up
     float* d_ypart = nullptr;
+    // column parts: for every part the fix-list index of each row (or -1), parts x rows, so that the merge of the partial
+    // vectors can apply the fix-ups of its rows itself (spmv_tail_multi_kernel); nullptr when a part has a long chain
+    int32_t* d_fix_of_row = nullptr;
     std::vector<void*> allocs;
 };
 
@@ -81,6 +84,7 @@ struct hispmv_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int batch_streams = 2;
     int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first
+    bool batch_lanes_lpt = false; // HISPMV_BATCH_LANES=lpt
     bool batch_graphs = true;    // HISPMV_BATCH_GRAPH=0: no HIP graph replay of batch calls
     // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
     // the three model_test layers: 49.9 us on one stream, 63.1 on two; the 20-matrix set: 353 -> 344 us with two)
@@ -113,12 +117,17 @@ struct hispmv_ctx {
         std::vector<float*> ys;                         // kind 1: where each part's cut rows live (y or a partial vector)
         std::vector<int32_t> rows;                      // kind 2
         std::vector<uint8_t> item_tiles;                // kind 0: parts per item (> 1: the XCD-pinned column tiles of one matrix)
+        std::vector<int32_t> fix_counts;                // kind 5 (fix-up + merge in one launch): short fix entries per part; rows = merged matrices
         void* d_table = nullptr;
+        void* d_table2 = nullptr;                       // kind 5: the TailMergeEntry table
+        int lane = 0;                                   // main launches: 0 = the caller's stream, k > 0 = side stream k - 1
+        int64_t weight = 0;                             // main launches: device bytes of the matrices in the grid
     };
     struct BatchPlan {
         std::vector<uint64_t> key;
         std::vector<BatchLaunch> launches;
         int64_t stream_bytes = 0;     // 8 B per entry of the call's sparse matrices: decides whether side streams pay
+        int lanes = 1;                // streams the main launches are spread over
         // HISPMV_BATCH_GRAPH=1 (experiment): the launches of a two-stream call captured once into a HIP graph and replayed
         hipGraphExec_t graph = nullptr;
         hipGraph_t graph_src = nullptr;      // the captured graph `graph` was instantiated from (kept: its node handles patch alpha)
@@ -186,7 +195,7 @@ void free_batch_plans(hispmv_ctx* c) {
     for (auto& p : c->batch_plans) {
         if (p.graph) { (void)hipGraphExecDestroy(p.graph); p.graph = nullptr; }
         if (p.graph_src) { (void)hipGraphDestroy(p.graph_src); p.graph_src = nullptr; }
-        for (auto& l : p.launches) dev_free(l.d_table);
+        for (auto& l : p.launches) { dev_free(l.d_table); dev_free(l.d_table2); }
     }
     c->batch_plans.clear();
 }
@@ -211,7 +220,7 @@ void free_matrix_device(Matrix& m) {
     for (void*& p : m.allocs) dev_free(p);
     m.allocs.clear();
     for (auto& p : m.parts) p.dev = SpmvDeviceMatrix{};
-    m.d_dense = nullptr; m.d_ypart = nullptr;
+    m.d_dense = nullptr; m.d_ypart = nullptr; m.d_fix_of_row = nullptr;
     m.loaded = false;
 }
 
@@ -610,6 +619,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     if (const char* env = std::getenv("HISPMV_BATCH_GRAPH")) c->batch_graphs = std::atoi(env) != 0;
     if (const char* env = std::getenv("HISPMV_BATCH_ORDER")) c->batch_order = !std::strcmp(env, "small_first") ? 1 : 0;
+    if (const char* env = std::getenv("HISPMV_BATCH_LANES")) c->batch_lanes_lpt = !std::strcmp(env, "lpt");
     if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) { c->batch_streams = std::max(1, std::min(3, std::atoi(env))); c->batch_streams_min_bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate(side)");
@@ -750,6 +760,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         Matrix& m = *mp;
         if (m.loaded) continue;
         int rc;
+        std::vector<std::vector<int32_t>> tts_fix_rows;       // tile streams: the rows cut into pieces, per part (fix list order)
         if (m.dense) {
             const float* d = nullptr;
             if ((rc = upload(c, m, m.dense_host.data(), m.dense_host.size(), &d)) != HISPMV_OK) return rc;
@@ -757,6 +768,8 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         } else if (m.format == 1) {
           for (Matrix::Part& p : m.parts) {
             TtsStream& ts = p.tts;
+            tts_fix_rows.emplace_back();
+            for (size_t k = 0; k + 3 < ts.fix.size(); k += 4) tts_fix_rows.back().push_back(ts.fix[k]);
             const uint8_t* dw = nullptr; const int32_t* dcb = nullptr; const uint16_t* dfl = nullptr; const int32_t* dci = nullptr;
             const TtsTile* dt = nullptr; const TtsBlock* db = nullptr;
             if ((rc = upload(c, m, ts.words.data(), ts.words.size(), &dw)) != HISPMV_OK) return rc;
@@ -857,6 +870,21 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             HIP_TRY(c, hipMalloc(&yp, (m.parts.size() - 1) * (size_t)kMaxBatch * m.rows * sizeof(float)));
             m.allocs.push_back(yp);
             m.d_ypart = (float*)yp;
+            // row -> fix entry of every part (short chains only: a part with a long chain keeps the two-launch tail)
+            bool fusable = m.parts.size() <= (size_t)kTailMaxParts;
+            for (auto& p : m.parts) fusable = fusable && (p.is_tts || p.fix_long.empty());
+            if (fusable) {
+                std::vector<int32_t> of((size_t)m.parts.size() * m.rows, -1);
+                for (size_t t = 0; t < m.parts.size(); ++t) {
+                    int32_t* o = of.data() + t * (size_t)m.rows;
+                    if (m.parts[t].is_tts) { const std::vector<int32_t>& f = tts_fix_rows[t]; for (size_t k = 0; k < f.size(); ++k) o[f[k]] = (int32_t)k; }
+                    else for (size_t k = 0; k < m.parts[t].fix_short.size(); ++k) o[m.parts[t].fix_short[k].row] = (int32_t)k;
+                }
+                const int32_t* d_of = nullptr;
+                if ((rc = upload(c, m, of.data(), of.size(), &d_of)) != HISPMV_OK) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                m.d_fix_of_row = const_cast<int32_t*>(d_of);
+            }
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // host copies are no longer needed
@@ -1105,6 +1133,86 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         if (!m.dense && m.format == 1)
             for (size_t t = 0; t < m.parts.size(); ++t) if (m.parts[t].tdev.n_fix > 0) fixrefs.push_back(Ref{i, t});
     }
+    // Lanes of the main launches: round-robin in launch order (default), or HISPMV_BATCH_LANES=lpt: longest-processing-time-
+    // first on the device bytes of their matrices with the heaviest lane on the CALLER'S stream, so that the tail launch
+    // follows the last-finishing main launch in stream order instead of behind an event of another stream.  Measured on the
+    // benchmark step (profiles/r3_experiments/step_structure.json): with plain launches the lpt lanes bring the tail from
+    // 11-12 us behind the last main kernel to 6 us, but the step does not get shorter (0.298-0.299 ms either way: the tile
+    // streams start behind the slice grid and run longer); replayed as a graph the runtime maps the branches to its own
+    // queues whatever the capture streams were, and round-robin order measures 0.298 against 0.302-0.303.
+    {
+        plan.lanes = plan.stream_bytes >= c->batch_streams_min_bytes ? c->batch_streams : 1;
+        std::vector<hispmv_ctx::BatchLaunch*> mains;
+        for (auto& l : plan.launches) {
+            if (l.kind == 0) for (const SpmvDeviceMatrix* d : l.parts) l.weight += d->n_slices * (int64_t)kWideSliceBytes;
+            if (l.kind == 3) for (const TtsEntry& e : l.tts) l.weight += (int64_t)e.m.n_tiles * 128 * 1024;
+            if (l.kind == 4) for (const GemvEntry& e : l.gemv) l.weight += 4 * (int64_t)e.rows * e.cols;
+            mains.push_back(&l);
+        }
+        plan.lanes = std::max(1, std::min<int>(plan.lanes, (int)mains.size()));
+        std::vector<hispmv_ctx::BatchLaunch*> by_weight = mains;
+        std::stable_sort(by_weight.begin(), by_weight.end(), [](const hispmv_ctx::BatchLaunch* x, const hispmv_ctx::BatchLaunch* y) { return x->weight > y->weight; });
+        if (c->batch_lanes_lpt) {
+            std::vector<int64_t> load((size_t)plan.lanes, 0);
+            for (hispmv_ctx::BatchLaunch* l : by_weight) {
+                const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                l->lane = k; load[(size_t)k] += l->weight;
+            }
+            const int heavy = (int)(std::max_element(load.begin(), load.end()) - load.begin());
+            for (hispmv_ctx::BatchLaunch* l : mains) l->lane = l->lane == heavy ? 0 : l->lane == 0 ? heavy : l->lane;
+        } else {
+            int k = 0;
+            for (hispmv_ctx::BatchLaunch* l : mains) l->lane = k++ % plan.lanes;       // launch order: tile streams, 1024-thread slices, 256-thread slices
+        }
+    }
+    // The tail: ONE launch that finishes the cut rows and merges the partial vectors of column-tiled matrices (which then
+    // apply their own fix-ups) when every tiled matrix of the call carries its row -> fix table and the tables fit one
+    // launch; otherwise a fix-up launch and a merge launch.
+    std::vector<int> tiled;
+    bool fused = !std::getenv("HISPMV_NO_FUSED_TAIL");
+    for (int i = 0; i < n; ++i) {
+        const Matrix& m = *c->mats[idx[i]];
+        if (m.dense || m.parts.size() < 2) continue;
+        tiled.push_back(i);
+        fused = fused && m.d_fix_of_row != nullptr;
+    }
+    if (fused) {
+        std::vector<Ref> plain;                                 // parts whose cut rows the fix-up blocks finish
+        for (const Ref& r : fixrefs) if (c->mats[idx[r.i]]->parts.size() < 2) plain.push_back(r);
+        fused = plain.size() <= (size_t)kMultiMax && tiled.size() <= (size_t)kMultiMax;
+        if (fused) {
+            hispmv_ctx::BatchLaunch l;
+            l.kind = 5;
+            std::vector<MultiFixEntry> fix;
+            std::vector<TailMergeEntry> mrg;
+            bool any = !tiled.empty();
+            for (const Ref& r : plain) {
+                SpmvDeviceMatrix& d = dev_of(r);
+                fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(r), d.n_fix_short, 0});
+                l.fix_counts.push_back(d.n_fix_short);
+                l.parts.push_back(&d); l.ys.push_back(out_of(r));               // (long chains: their own launches behind the tail)
+                any = any || d.n_fix_short > 0 || d.n_fix_long > 0;
+            }
+            for (int i : tiled) {
+                Matrix& m = *c->mats[idx[i]];
+                TailMergeEntry e{};
+                e.y = d_y[i]; e.parts = m.d_ypart; e.part_stride = (long long)kMaxBatch * m.rows; e.n_parts = (int32_t)m.parts.size() - 1; e.rows = m.rows;
+                e.fix_of_row = m.d_fix_of_row;
+                for (size_t t = 0; t < m.parts.size(); ++t) { e.fix[t] = m.parts[t].dev.fix_short; e.carry[t] = m.parts[t].dev.carry; }
+                mrg.push_back(e);
+                l.rows.push_back(m.rows);
+            }
+            if (!any) return HISPMV_OK;
+            plan.launches.push_back(std::move(l));
+            hispmv_ctx::BatchLaunch& L = plan.launches.back();
+            if (!fix.empty() && (rc = upload_table(L, fix.data(), fix.size() * sizeof(MultiFixEntry))) != HISPMV_OK) return rc;
+            if (!mrg.empty()) {
+                HIP_TRY(c, hipMalloc(&L.d_table2, mrg.size() * sizeof(TailMergeEntry)));
+                HIP_TRY(c, hipMemcpy(L.d_table2, mrg.data(), mrg.size() * sizeof(TailMergeEntry), hipMemcpyHostToDevice));
+            }
+            return HISPMV_OK;
+        }
+    }
     for (size_t k = 0; k < fixrefs.size(); k += kMultiMax) {    // fix-up of the cut rows
         hispmv_ctx::BatchLaunch l;
         l.kind = 1;
@@ -1132,9 +1240,8 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         merges.clear(); merge_rows.clear();
         return r2;
     };
-    for (int i = 0; i < n; ++i) {                               // merge of the column-tile partial vectors
+    for (int i : tiled) {                                       // merge of the column-tile partial vectors
         Matrix& m = *c->mats[idx[i]];
-        if (m.dense || m.parts.size() < 2) continue;
         merges.push_back(MultiMergeEntry{d_y[i], m.d_ypart, (long long)kMaxBatch * m.rows, (int32_t)m.parts.size() - 1, m.rows});
         merge_rows.push_back(m.rows);
         if ((int)merges.size() == kMultiMax && (rc = flush_merges()) != HISPMV_OK) return rc;
@@ -1181,23 +1288,21 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
         if (c->batch_plans.size() >= 16) free_batch_plans(c);      // callers that keep changing their vectors: start over
         c->batch_plans.emplace_back();
         c->batch_plans.back().key = key;
+        for (int i = 0; i < n; ++i) {
+            const Matrix& mi = *c->mats[idx[i]];
+            c->batch_plans.back().stream_bytes += mi.dense ? 4 * (int64_t)mi.rows * mi.cols : 8 * mi.nnz;
+        }
         const int rc = build_batch_plan(c, c->batch_plans.back(), n, idx, d_x, bias, d_y, beta);
         if (rc != HISPMV_OK) {                                      // nothing half-built stays behind
-            for (auto& l : c->batch_plans.back().launches) dev_free(l.d_table);
+            for (auto& l : c->batch_plans.back().launches) { dev_free(l.d_table); dev_free(l.d_table2); }
             c->batch_plans.pop_back();
             return rc;
         }
         plan = &c->batch_plans.back();
-        for (int i = 0; i < n; ++i) {
-            const Matrix& mi = *c->mats[idx[i]];
-            plan->stream_bytes += mi.dense ? 4 * (int64_t)mi.rows * mi.cols : 8 * mi.nnz;
-        }
     }
     // main launches (kinds 0 and 3) are independent of each other: spread over the caller's stream and the side streams;
     // the fix-up and merge launches follow on the caller's stream behind a join
-    int n_main = 0;
-    for (const auto& l : plan->launches) n_main += l.kind == 0 || l.kind == 3 || l.kind == 4;
-    const int lanes = plan->stream_bytes >= c->batch_streams_min_bytes ? std::min(c->batch_streams, n_main) : 1;
+    const int lanes = plan->lanes;
     // the launches, as one function of the stream: main launches spread over the caller's stream and the side streams (forked
     // from / joined to it with events), fix-up and merge behind the join
     auto enqueue = [&]() -> int {
@@ -1205,13 +1310,12 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
             HIP_TRY(c, hipEventRecord(c->ev_fork, s));
             for (int i = 0; i + 1 < lanes; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
         }
-        int k_main = 0;
         bool joined = lanes <= 1;
         for (const auto& l : plan->launches) {
             hipError_t e = hipSuccess;
             const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
             hipStream_t ls = s;
-            if (is_main && lanes > 1) { const int lane = k_main++ % lanes; ls = lane == 0 ? s : c->side[lane - 1]; }
+            if (is_main && lanes > 1) ls = l.lane == 0 ? s : c->side[l.lane - 1];
             if (!is_main && !joined) {
                 for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
                 joined = true;
@@ -1220,8 +1324,14 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
             else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const TtsEntry*)l.d_table, alpha, ls);
             else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
             else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
+            else if (l.kind == 5) {
+                e = launch_tail_multi(l.fix_counts.data(), (int)l.fix_counts.size(), (const MultiFixEntry*)l.d_table, l.rows.data(), (int)l.rows.size(),
+                                      (const TailMergeEntry*)l.d_table2, alpha, ls);
+                for (size_t q = 0; e == hipSuccess && q < l.parts.size(); ++q)       // rows that span more than 32 slices: a wavefront per row
+                    if (l.parts[q]->n_fix_long > 0) e = launch_fixup_long(*l.parts[q], l.ys[q], alpha, ls);
+            }
             else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
-            if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : "launch_merge_multi");
+            if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : l.kind == 5 ? "launch_tail_multi" : "launch_merge_multi");
         }
         if (!joined)
             for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }

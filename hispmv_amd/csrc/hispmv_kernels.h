@@ -79,6 +79,17 @@ struct MultiEntry {
 };
 struct MultiFixEntry { const int4* fix; const float* carry; float* y; int32_t n, pad; };
 struct MultiMergeEntry { float* y; const float* parts; long long part_stride; int32_t n_parts, rows; };
+// The tail of a batch call in ONE launch (spmv_tail_multi_kernel): the fix-up of the cut rows of every matrix part, and -- for
+// matrices with column parts -- the merge of their partial vectors, which then applies the fix-ups of ITS rows itself:
+//   y[i] = (y[i] + alpha * chain_0(i)) + (part_1[i] + alpha * chain_1(i)) + ...      (the bits of fix-up launch + merge launch)
+// fix_of_row: (n_parts + 1) x rows int32, index into that part's fix list or -1.
+constexpr int kTailMaxParts = 9;      // tile 0 + up to 8 column tiles
+struct TailMergeEntry {
+    float* y; const float* parts; long long part_stride; int32_t n_parts, rows;
+    const int32_t* fix_of_row;
+    const int4* fix[kTailMaxParts];
+    const float* carry[kTailMaxParts];
+};
 // ... and, as a kernel argument, where each entry's workgroups begin in the grid (begin[n] = grid size)
 // An ITEM of a multi launch is one table entry, or -- `tiles[k]` = 2, 4 or 8 -- the column tiles of one matrix that
 // gather x through L2: consecutive table entries from `first[k]`, pinned to disjoint XCD subsets.  Workgroups are dealt
@@ -126,6 +137,11 @@ hipError_t launch_merge_parts(float* y, const float* parts, int n_parts, int64_t
 hipError_t launch_merge_multi(const int32_t* rows, int n, const MultiMergeEntry* d_table, hipStream_t stream);
 hipError_t launch_fixup_multi(const SpmvDeviceMatrix* const* parts, float* const* ys, int n, const MultiFixEntry* d_fix_table,
                               float alpha, hipStream_t stream);
+// The long chains of one part (a wavefront per row that spans more than kFixShortMax slices).
+hipError_t launch_fixup_long(const SpmvDeviceMatrix& m, float* y, float alpha, hipStream_t stream);
+// Fix-up (n_fix parts, short chains only) and merge (n_merge matrices with column parts) in one launch; tables on the device.
+hipError_t launch_tail_multi(const int32_t* fix_counts, int n_fix, const MultiFixEntry* d_fix_table, const int32_t* merge_rows, int n_merge,
+                             const TailMergeEntry* d_merge_table, float alpha, hipStream_t stream);
 
 // Transposed tile stream: y = alpha*A*x + beta*bias in ONE launch (one workgroup of 1024 threads per row tile; no carry
 // buffers, no fix-up launch); launch_tts_multi: the tiles of `n` matrices in one grid (d_table: device copy of TtsEntry).

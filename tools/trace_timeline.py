@@ -9,7 +9,7 @@ ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 steps, cur = [], []
 for e in ev:
     cur.append(e)
-    if "merge_multi" in e[2]:
+    if "merge_multi" in e[2] or "tail_multi" in e[2]:
         steps.append(cur); cur = []
 for st in steps[-want:]:
     t0 = st[0][0]
