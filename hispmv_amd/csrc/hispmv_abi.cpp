@@ -272,12 +272,17 @@ int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
     return (int32_t)w;
 }
 
-void finish_part(Matrix::Part& p, int n_cus) {
+// The launch plan of a part, then its device layout.  Two steps: a matrix that becomes a tile stream needs the plan (the
+// decision reads it) but not the device layout of the slice stream it drops (0.14 s on soc-Pokec's shape).
+void plan_part(Matrix::Part& p, int n_cus) {
     for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
     p.plan = make_plan(p.st, n_cus);     // also rewrites the column field of LDS-staged groups
+}
+void pack_part(Matrix::Part& p) {
     p.dstream = pack_device_stream(p.st, p.plan);
     p.st.words = std::vector<uint64_t>();   // the device layout replaces the host words
 }
+void finish_part(Matrix::Part& p, int n_cus) { plan_part(p, n_cus); pack_part(p); }
 
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
 // "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).
@@ -287,7 +292,8 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     m->rows = csr.rows; m->cols = csr.cols; m->nnz = csr.nnz();
     m->parts.emplace_back();
     m->parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
-    finish_part(m->parts[0], c->n_cus);
+    plan_part(m->parts[0], c->n_cus);            // (its device layout: once the format is decided, below)
+    bool whole_packed = false;
     // Column tiling when the whole-matrix plan has to gather x through L2:
     //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
     //  * x larger than an XCD's L2: L2-sized tiles.
@@ -449,6 +455,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         }
     }
     csr = Csr{};
+    if (!whole_packed && tw == 0) pack_part(m->parts[0]);       // the whole-matrix stream stays: its device layout now
     for (auto& p : m->parts) {
         m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
         m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
@@ -522,10 +529,23 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
         if (e != hipSuccess) return hip_fail(c, e, "launch_gemv_batched");
         return HISPMV_OK;
     }
-    if (m.format == 1) {          // transposed tile stream: one launch per vector (same bits as a single-vector call)
-        for (int64_t k = 0; k < vecs; ++k) {
-            const int rc = launch_matrix(c, m, d_x + k * m.cols, d_bias, d_y + k * m.rows, alpha, beta, s);
-            if (rc != HISPMV_OK) return rc;
+    if (m.format == 1) {          // transposed tile stream: up to 8 vectors per launch (same bits as a single-vector call each)
+        int64_t k = 0;
+        while (k < vecs) {
+            // 4 or 2 vectors through every pass over the words where the tiles are small enough; else up to 8 in one launch, one after the other
+            int nv = 1;
+            if (m.parts.size() == 1 && !m.parts[0].tdev.zero_fill) {
+                nv = tts_batch_width(m.parts[0].tdev, vecs - k);
+                if (nv < 2) nv = (int)std::min<int64_t>(vecs - k, kTtsMaxVectors);
+            }
+            if (nv >= 2) {
+                hipError_t e = launch_tts_batched(m.parts[0].tdev, nv, d_x + k * m.cols, d_bias, d_y + k * m.rows, alpha, beta, s);
+                if (e != hipSuccess) return hip_fail(c, e, "launch_tts_batched");
+            } else {
+                const int rc = launch_matrix(c, m, d_x + k * m.cols, d_bias, d_y + k * m.rows, alpha, beta, s);
+                if (rc != HISPMV_OK) return rc;
+            }
+            k += nv;
         }
         return HISPMV_OK;
     }
@@ -785,9 +805,10 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 const int32_t* dfix = nullptr;
                 if ((rc = upload(c, m, ts.fix.data(), ts.fix.size(), &dfix)) != HISPMV_OK) return rc;
                 void* carry = nullptr;
-                HIP_TRY(c, hipMalloc(&carry, (size_t)std::max(ts.n_carry, 1) * sizeof(float)));
+                HIP_TRY(c, hipMalloc(&carry, (size_t)std::max(ts.n_carry, 1) * kTtsMaxVectors * sizeof(float)));      // one set per vector of a batched launch
                 m.allocs.push_back(carry);
-                HIP_TRY(c, hipMemsetAsync(carry, 0, (size_t)std::max(ts.n_carry, 1) * sizeof(float), c->stream));
+                HIP_TRY(c, hipMemsetAsync(carry, 0, (size_t)std::max(ts.n_carry, 1) * kTtsMaxVectors * sizeof(float), c->stream));
+                d.n_carry = ts.n_carry;
                 d.fix = (const int4*)dfix; d.n_fix = (int32_t)(ts.fix.size() / 4); d.carry = (float*)carry;
                 // (the same three fields where the multi-matrix fix-up launch looks for them)
                 p.dev.fix_short = d.fix; p.dev.n_fix_short = d.n_fix; p.dev.carry = d.carry; p.dev.n_fix_long = 0;
@@ -795,6 +816,11 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = ts.geometry.threads;
             d.zero_fill = ts.geometry.zero_fill ? 1 : 0;
             d.staging_floats = ts.geometry.max_slots + 64;        // (the dummy slot of padding words sits behind the last real one)
+            d.batch_stage_floats = ((ts.max_slots + kTtsChunk - 1) / kTtsChunk) * kTtsChunk + 64;
+            // x in the LDS for short x (HISPMV_TTS_XLDS=1; off by default -- measured slower on the 1024 x 8192 layer of
+            // apps/model_test.py: 16.7 against 15.1 us alone, 8 vectors 74 against 58 us: that layer's tiles are latency chains
+            // of 8 K elements, not gather-bound)
+            d.xlds_floats = (m.cols <= kTtsXldsMax && std::getenv("HISPMV_TTS_XLDS")) ? ((m.cols + 63) & ~63) : 0;
             if (((size_t)d.acc_floats + (size_t)d.staging_floats + 64) * 4 > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: tile stream exceeds the LDS of a CU");
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             p.tts = TtsStream{};
@@ -1019,11 +1045,13 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             if (rc0 != HISPMV_OK) return rc0;
         }
     }
+    // (+ 1 << 24: matrices whose x the kernel keeps in the LDS -- another LDS size, another kernel instantiation)
+    auto tts_class = [](const Matrix& m) { return m.parts[0].tdev.staging_floats + (m.parts.size() == 1 && tts_x_in_lds(m.parts[0].tdev, 1) ? (1 << 24) : 0); };
     std::vector<int> tts_classes;                // staging size = the geometry (hispmv_tts.h): small 13 K, standard 28 K, tall 23 K, paired 11 K
     for (int i = 0; i < n; ++i) {
         const Matrix& m = *c->mats[idx[i]];
         if (m.dense || m.format != 1) continue;
-        const int cls = m.parts[0].tdev.staging_floats;
+        const int cls = tts_class(m);
         if (std::find(tts_classes.begin(), tts_classes.end(), cls) == tts_classes.end()) tts_classes.push_back(cls);
     }
     std::sort(tts_classes.begin(), tts_classes.end());
@@ -1044,7 +1072,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         for (int i = 0; i < n; ++i) {
             const Matrix& m = *c->mats[idx[i]];
             if (m.dense || m.format != 1) continue;
-            if (m.parts[0].tdev.staging_floats == geometry) order.push_back(i);
+            if (tts_class(m) == geometry) order.push_back(i);
         }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
             const Matrix& ma = *c->mats[idx[a]]; const Matrix& mb = *c->mats[idx[b]];

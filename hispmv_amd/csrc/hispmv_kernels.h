@@ -45,7 +45,10 @@ struct TtsDeviceMatrix {
     int32_t n_fix = 0;
     int32_t zero_fill = 0;              // 1: rows absent from a block have no stream word, the staging is kept zero-filled (TtsGeometry::zero_fill)
     int32_t n_tiles = 0, rows = 0, cols = 0;
+    int32_t n_carry = 0;                // carry tiles; the carry buffer holds kTtsMaxVectors x n_carry (vector v of a batched launch: carry + v * n_carry)
     int32_t acc_floats = 0, staging_floats = 0;    // LDS: accumulators (max rows of a tile), staging (max slots of a block + dummy)
+    int32_t xlds_floats = 0;                       // > 0: x is short enough for the LDS (cols rounded up to 64; kTtsXldsMax)
+    int32_t batch_stage_floats = 0;                // per-vector staging area of the NV-vector kernel: the LARGEST block of this matrix in whole chunks + 64
     int32_t threads = 512;                         // workgroup size (hispmv_tts.h: kTtsThreads)
 };
 struct TtsEntry {                       // multi-matrix launch: one per matrix
@@ -146,6 +149,13 @@ hipError_t launch_tail_multi(const int32_t* fix_counts, int n_fix, const MultiFi
 // Transposed tile stream: y = alpha*A*x + beta*bias in ONE launch (one workgroup of 1024 threads per row tile; no carry
 // buffers, no fix-up launch); launch_tts_multi: the tiles of `n` matrices in one grid (d_table: device copy of TtsEntry).
 hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream);
+// `nv` <= kTtsMaxVectors vectors in one launch (x + v*cols -> y + v*rows, shared bias): per vector bitwise equal to launch_tts.
+constexpr int kTtsMaxVectors = 8;
+constexpr int kTtsXldsMax = 16 * 1024;      // floats of x the tile-stream kernels keep in the LDS (64 KiB)
+bool tts_x_in_lds(const TtsDeviceMatrix& m, int nv);
+// 4 / 2: that many vectors can share each pass over the words (their accumulators and staging areas fit the LDS together); 1: not
+int tts_batch_width(const TtsDeviceMatrix& m, int64_t vecs);
+hipError_t launch_tts_batched(const TtsDeviceMatrix& m, int nv, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream);
 // (launch_tts finishes the rows it cut into pieces with a second tiny launch; in a multi-matrix call they ride in launch_fixup_multi)
 // `item_parts` (n_items entries summing to n; NULL = all 1): 2 = the two column parts of one matrix, consecutive entries,
 // pinned to XCDs 0-3 / 4-7 so that an XCD's L2 holds one part's half of x.

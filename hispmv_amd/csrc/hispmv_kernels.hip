@@ -1214,18 +1214,31 @@ __device__ __forceinline__ void tts_request(TtsSlice& s, const char* words, int 
     for (int j = 0; j < kSliceSteps; ++j) s.m[j] = load_words(pv + 256 + j * 64);
 }
 
-template <bool HAS_BETA>
+// NV > 1: NV input vectors per pass over the tile's words (FpgaHandle::linear with num_vecs > 1 on a matrix whose tiles are
+// small enough: NV copies of the accumulators and of the staging fit the LDS).  Inside phase A a wavefront takes its slice
+// through the vectors one after the other -- gathers from x + v*cols, products into staging area v -- and phase B reduces
+// every staging area into accumulator set v: the barriers, the slice loads, the flag words and the latency chain of a block
+// are shared by the NV vectors, and every vector sees exactly the arithmetic of the single-vector kernel (same bits).
+// The staging areas are `stage_stride` floats apart (the matrix's largest block rounded up to whole chunks, plus the dummy
+// slot padding words write to: their slot number -- the geometry's maximum -- is clamped to it).
+// XLDS: x is short enough (M.xlds_floats = cols rounded up, <= kTtsXldsMax) to sit in the LDS next to the accumulators and the
+// staging: the workgroup copies it there once (coalesced) and phase A gathers with ds_read_b32 -- the vector cache takes the
+// lanes of a scattered global gather one per cycle or two, the LDS 32 per cycle.  The wide, short layers of
+// apps/model_test.py (1024 x 8192).  Staging areas are sized by the matrix's largest block (batch_stage_floats), as for NV > 1.
+template <bool HAS_BETA, bool ZERO_FILL = false, int NV = 1, bool XLDS = false>
 __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const float* __restrict__ x, const float* bias, float* y,
                                               float alpha, float beta, int tile_index) {
     extern __shared__ float xs[];
-    float* const acc = xs;
-    float* const staging = xs + M.acc_floats;
-    float* const tails = staging + M.staging_floats;
+    float* const acc0 = xs;
+    float* const staging0 = xs + M.acc_floats * NV;
+    const int stage_stride = (NV > 1 || XLDS) ? M.batch_stage_floats : M.staging_floats;
+    float* const tails = staging0 + stage_stride * NV;
+    float* const xw0 = tails + 64 * NV;                      // XLDS: NV copies of x, xlds_floats apart
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform: table reads become scalar loads
     const int n_waves = blockDim.x >> 6;
     constexpr int kE = kSliceSteps * kLaneElems;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, M.cols * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, M.cols * NV * 4, 0x00020000);
     const char* const words = (const char*)M.words;
     const int4 tile = load_int4(M.tiles + tile_index);
     const int row0 = tile.x, n_rows = tile.y, block_begin = tile.z, n_blocks = tile.w;      // row0 < 0: carry tile (one row)
@@ -1240,18 +1253,45 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         if (wave < blk.y) { tts_request(wA, words, blk.x + wave, lane); cbA = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave); }
         if (wave + n_waves < blk.y) { tts_request(wB, words, blk.x + wave + n_waves, lane); cbB = *(const HISPMV_GLOBAL int*)(M.col_base + blk.x + wave + n_waves); }
     }
-    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) acc[i] = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        for (int i = threadIdx.x; i < n_rows; i += blockDim.x) acc0[v * M.acc_floats + i] = 0.0f;
+    if (XLDS) {
+        // all loads of a thread in flight, then the LDS writes (a load-store loop waited out one L2 round trip per 1024 floats)
+        const HISPMV_GLOBAL float* xg = (const HISPMV_GLOBAL float*)x;
+        constexpr int kU = kTtsXldsMax / 1024;           // dwords per thread of a 1024-thread workgroup
+        for (int v = 0; v < NV; ++v) {
+            float t[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) { const int i = (int)threadIdx.x + u * (int)blockDim.x; t[u] = i < M.cols ? xg[(size_t)v * M.cols + i] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) { const int i = (int)threadIdx.x + u * (int)blockDim.x; if (i < M.xlds_floats) xw0[v * M.xlds_floats + i] = t[u]; }
+        }
+    }
     // zero-fill geometry (hispmv_tts.h): rows absent from a block own a slot of its row-major order but no stream word --
     // the staging is all zero whenever a phase A starts: zeroed here, and phase B writes zeros back over what it has read
-    const bool zero_fill = M.zero_fill != 0;
-    if (zero_fill)
-        for (int i = threadIdx.x; i < (M.staging_floats >> 2); i += blockDim.x) ((float4*)staging)[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    // (a template parameter: as a run-time flag its zero vector lived across the block loop and the multi-matrix kernel spilled)
+    if (ZERO_FILL)
+        for (int i = threadIdx.x; i < ((stage_stride * NV) >> 2); i += blockDim.x) ((float4*)staging0)[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
 
     // phase A for one slice: gathers, products -> staging, the request that reuses the buffer (next >= 0)
     auto phase_a = [&](TtsSlice& w, int& cb, int next) {
-        const int base = __builtin_amdgcn_readfirstlane(cb) << 2;
+        const int base0 = __builtin_amdgcn_readfirstlane(cb) << 2;
+        const unsigned dummy = (unsigned)stage_stride - 64u;      // (NV > 1: where padding words go in a staging area)
+#pragma unroll 1
+        for (int v = 0; v < NV; ++v) {      // (not unrolled: the gathers of several vectors in flight at once spilled registers)
+        const int base = base0 + v * (M.cols << 2);
+        float* const staging = staging0 + v * stage_stride;
         float xv[kE];
+        if (XLDS) {
+            const float* const xw = xw0 + v * M.xlds_floats + (base0 >> 2);
+#pragma unroll
+            for (int j = 0; j < kSliceSteps; ++j) {
+                xv[4 * j + 0] = xw[w.m[j].x >> 16]; xv[4 * j + 1] = xw[w.m[j].y >> 16];
+                xv[4 * j + 2] = xw[w.m[j].z >> 16]; xv[4 * j + 3] = xw[w.m[j].w >> 16];
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             xv[4 * j + 0] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].x >> 16) << 2, base, 0));
@@ -1259,14 +1299,23 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
             xv[4 * j + 2] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].z >> 16) << 2, base, 0));
             xv[4 * j + 3] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].w >> 16) << 2, base, 0));
         }
+        }
         // products -> staging[slot] (the transposition), THEN the request that reuses the buffer: the slots are read from
         // the buffer itself (16 registers less than keeping them across the request; two buffers + 16 products fit 128)
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
-            staging[w.m[j].x & 0xffffu] = i2f((int)w.v[j].x) * xv[4 * j + 0];
-            staging[w.m[j].y & 0xffffu] = i2f((int)w.v[j].y) * xv[4 * j + 1];
-            staging[w.m[j].z & 0xffffu] = i2f((int)w.v[j].z) * xv[4 * j + 2];
-            staging[w.m[j].w & 0xffffu] = i2f((int)w.v[j].w) * xv[4 * j + 3];
+            if (NV > 1 || XLDS) {
+                staging[min(w.m[j].x & 0xffffu, dummy)] = i2f((int)w.v[j].x) * xv[4 * j + 0];
+                staging[min(w.m[j].y & 0xffffu, dummy)] = i2f((int)w.v[j].y) * xv[4 * j + 1];
+                staging[min(w.m[j].z & 0xffffu, dummy)] = i2f((int)w.v[j].z) * xv[4 * j + 2];
+                staging[min(w.m[j].w & 0xffffu, dummy)] = i2f((int)w.v[j].w) * xv[4 * j + 3];
+            } else {
+                staging[w.m[j].x & 0xffffu] = i2f((int)w.v[j].x) * xv[4 * j + 0];
+                staging[w.m[j].y & 0xffffu] = i2f((int)w.v[j].y) * xv[4 * j + 1];
+                staging[w.m[j].z & 0xffffu] = i2f((int)w.v[j].z) * xv[4 * j + 2];
+                staging[w.m[j].w & 0xffffu] = i2f((int)w.v[j].w) * xv[4 * j + 3];
+            }
+        }
         }
         asm volatile("" ::: "memory");
         if (next >= 0) {
@@ -1276,13 +1325,16 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
     };
     // phase B for one chunk of 1024 staged products in row-major order
     auto phase_b = [&](int c, int2 ci, unsigned ends) {
+#pragma unroll 1
+        for (int v = 0; v < NV; ++v) {
+        float* const acc = acc0 + v * M.acc_floats;
         int row = __builtin_amdgcn_readfirstlane(ci.x);
-        const float4* st4 = (const float4*)(staging + c * kTtsChunkSlots) + lane;
+        const float4* st4 = (const float4*)(staging0 + v * stage_stride + c * kTtsChunkSlots) + lane;
         float carry_step = 0.0f;
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             const float4 q = st4[j * 64];
-            if (zero_fill) ((float4*)st4)[j * 64] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (ZERO_FILL) ((float4*)st4)[j * 64] = float4{0.0f, 0.0f, 0.0f, 0.0f};
             const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
             bool e[kLaneElems];
             int below = 0, total = 0;
@@ -1309,7 +1361,8 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
                 if (e[k]) acc[r[k]] = a[k] + tj[k];
             row += total;
         }
-        if (lane == 0) tails[c] = carry_step;
+        if (lane == 0) tails[v * 64 + c] = carry_step;
+        }
     };
 
     for (int b = 0; b < n_blocks; ++b) {
@@ -1353,24 +1406,40 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         // before it follow here, in chunk order (one lane per chunk; a block has at most 48 chunks)
         if (wave == 0 && lane < n_chunks) {
             if (ciT.y > 0) {
-                float s = 0.0f;
-                for (int k = lane - ciT.y; k < lane; ++k) s += tails[k];
-                acc[ciT.x] = acc[ciT.x] + s;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float* const acc = acc0 + v * M.acc_floats;
+                    float s = 0.0f;
+                    for (int k = lane - ciT.y; k < lane; ++k) s += tails[v * 64 + k];
+                    acc[ciT.x] = acc[ciT.x] + s;
+                }
             }
         }
         blk = nxt;
         // (the next phase A writes staging only; tails and acc are next touched behind the barrier that follows it)
     }
     __syncthreads();
-    if (row0 < 0) {         // a piece of a long row: its raw sum waits in carry[] for the fix-up launch
-        if (threadIdx.x == 0) *(HISPMV_GLOBAL float*)(M.carry + (-row0 - 1)) = acc[0];
+    if (row0 < 0) {         // a piece of a long row: its raw sum waits in carry[] for the fix-up launch (vector v: carry + v * n_carry)
+        if ((int)threadIdx.x < NV) *(HISPMV_GLOBAL float*)(M.carry + (size_t)threadIdx.x * M.n_carry + (-row0 - 1)) = acc0[threadIdx.x * M.acc_floats];
         return;
     }
-    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) {
-        const float t = acc[i];
-        if (HAS_BETA) *(HISPMV_GLOBAL float*)(y + row0 + i) = alpha * t + beta * *(const HISPMV_GLOBAL float*)(bias + row0 + i);
-        else *(HISPMV_GLOBAL float*)(y + row0 + i) = alpha * t;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float* const acc = acc0 + v * M.acc_floats;
+        float* const yv = y + (size_t)v * M.rows;
+        for (int i = threadIdx.x; i < n_rows; i += blockDim.x) {
+            const float t = acc[i];
+            if (HAS_BETA) *(HISPMV_GLOBAL float*)(yv + row0 + i) = alpha * t + beta * *(const HISPMV_GLOBAL float*)(bias + row0 + i);
+            else *(HISPMV_GLOBAL float*)(yv + row0 + i) = alpha * t;
+        }
     }
+}
+
+// NV vectors per pass over the words (tts_tile_body<., ., NV>), x through the cache or from the LDS
+template <bool HAS_BETA, int NV, bool XLDS>
+__global__ __launch_bounds__(1024) void spmv_tts_nv_kernel(TtsDeviceMatrix M, const float* __restrict__ x, const float* bias, float* y,
+                                                           float alpha, float beta) {
+    tts_tile_body<HAS_BETA, false, NV, XLDS>(M, x, bias, y, alpha, beta, (int)blockIdx.x);
 }
 
 template <bool HAS_BETA>
@@ -1379,6 +1448,25 @@ __global__ __launch_bounds__(1024) void spmv_tts_kernel(TtsDeviceMatrix M, const
     tts_tile_body<HAS_BETA>(M, x, bias, y, alpha, beta, (int)blockIdx.x);
 }
 
+// `nv` vectors in ONE launch (FpgaHandle::linear with num_vecs > 1; the reference relaunches its kernel per vector,
+// fpga_handle.cpp:366-379): a workgroup takes its tile through the vectors one after the other -- vector v reads x + v*cols
+// and writes y + v*rows, with exactly the arithmetic of the single-vector kernel (same bits).  The tile's words are read
+// from HBM for the first vector and from L2 / the Infinity Cache for the others when the matrix fits there (the model
+// layers do), and the launch latency is paid once.  (Keeping a block's slices in registers across the vectors instead
+// -- two slice buffers live through phase B -- spilled 236 bytes per lane at the 128 registers a 16-wavefront workgroup has.)
+template <bool HAS_BETA>
+__global__ __launch_bounds__(1024) void spmv_tts_batched_kernel(TtsDeviceMatrix M, const float* __restrict__ x, const float* bias, float* y,
+                                                                float alpha, float beta, int nv) {
+#pragma unroll 1
+    for (int v = 0; v < nv; ++v) {
+        tts_tile_body<HAS_BETA>(M, x + (size_t)v * M.cols, bias, y + (size_t)v * M.rows, alpha, beta, (int)blockIdx.x);
+        __syncthreads();          // the next vector's prologue zeroes the accumulators this one's epilogue reads
+        // a carry tile of vector v writes carry[-row0 - 1]; the fix-up launch reads one set per vector
+        M.carry += M.n_carry;
+    }
+}
+
+template <bool ZERO_FILL, bool XLDS = false>
 __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
     int k = 0;
 #pragma unroll 1
@@ -1396,9 +1484,12 @@ __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __
     }
     const TtsEntry e = table[entry];      // (once per workgroup; every load in the body is cast to the global address space)
     if (tile >= e.m.n_tiles) return;      // (a part with fewer tiles than its sibling)
-    if (e.beta != 0.0f) tts_tile_body<true>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
-    else tts_tile_body<false>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
+    if (e.beta != 0.0f) tts_tile_body<true, ZERO_FILL, 1, XLDS>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
+    else tts_tile_body<false, ZERO_FILL, 1, XLDS>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
 }
+
+template <int NV, bool XLDS>
+static hipError_t launch_tts_nv2(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream);
 
 static size_t tts_lds_bytes(const TtsDeviceMatrix& m) { return ((size_t)m.acc_floats + (size_t)m.staging_floats + 64) * sizeof(float); }
 
@@ -1413,11 +1504,83 @@ hipError_t launch_tts(const TtsDeviceMatrix& m, const float* x, const float* bia
         raised = true;
     }
     const size_t lds = tts_lds_bytes(m);
-    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 - 256 || m.zero_fill) return hipErrorInvalidValue;      // (zero-fill geometries have column parts: launch_tts_multi)
+    if (tts_x_in_lds(m, 1)) {           // a short x: gathered from the LDS
+        hipError_t e = launch_tts_nv2<1, true>(m, x, bias, y, alpha, beta, stream);
+        if (e != hipSuccess) return e;
+    } else
     if (beta != 0.0f) hipLaunchKernelGGL(spmv_tts_kernel<true>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, bias, y, alpha, beta);
     else hipLaunchKernelGGL(spmv_tts_kernel<false>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, y, y, alpha, beta);
     if (m.n_fix > 0)
         hipLaunchKernelGGL(spmv_fixup_short_kernel, dim3((m.n_fix + 255) / 256), dim3(256), 0, stream, m.fix, m.n_fix, m.carry, y, alpha, 0LL, 0LL);
+    return hipGetLastError();
+}
+
+// LDS of the NV-vector / x-in-LDS kernels: per vector the accumulators, one staging area (largest block of the matrix), 64
+// tails and -- xlds -- a copy of x
+static size_t tts_nv_lds_bytes(const TtsDeviceMatrix& m, int nv, bool xlds) {
+    return ((size_t)m.acc_floats + (size_t)m.batch_stage_floats + 64 + (xlds ? (size_t)m.xlds_floats : 0)) * nv * sizeof(float);
+}
+bool tts_x_in_lds(const TtsDeviceMatrix& m, int nv) {
+    return !m.zero_fill && m.xlds_floats > 0 && m.batch_stage_floats > 0 && tts_nv_lds_bytes(m, nv, true) <= 160 * 1024 - 256;
+}
+int tts_batch_width(const TtsDeviceMatrix& m, int64_t vecs) {
+    if (vecs < 2 || m.zero_fill || m.batch_stage_floats <= 0) return 1;
+    for (int nv = 4; nv >= 2; nv >>= 1)         // x from the LDS first: fewer vectors per pass, but no gather through the cache
+        if (nv <= vecs && tts_x_in_lds(m, nv)) return nv;
+    for (int nv = 4; nv >= 2; nv >>= 1) {
+        if (nv > vecs) continue;
+        if ((int64_t)m.cols * nv >= (1 << 30) || (int64_t)m.rows * nv >= (1 << 30)) continue;
+        if (tts_nv_lds_bytes(m, nv, false) <= 160 * 1024 - 256) return nv;
+    }
+    return 1;
+}
+
+template <bool HAS_BETA, int NV, bool XLDS>
+static hipError_t launch_tts_nv(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream) {
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)spmv_tts_nv_kernel<HAS_BETA, NV, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    const size_t lds = tts_nv_lds_bytes(m, NV, XLDS);
+    hipLaunchKernelGGL((spmv_tts_nv_kernel<HAS_BETA, NV, XLDS>), dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, HAS_BETA ? bias : y, y, alpha, beta);
+    return hipGetLastError();
+}
+template <int NV, bool XLDS>
+static hipError_t launch_tts_nv2(const TtsDeviceMatrix& m, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream) {
+    return beta != 0.0f ? launch_tts_nv<true, NV, XLDS>(m, x, bias, y, alpha, beta, stream) : launch_tts_nv<false, NV, XLDS>(m, x, bias, y, alpha, beta, stream);
+}
+
+hipError_t launch_tts_batched(const TtsDeviceMatrix& m, int nv, const float* x, const float* bias, float* y, float alpha, float beta, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (nv < 2 || nv > kTtsMaxVectors || m.zero_fill) return hipErrorInvalidValue;
+    if (m.n_tiles <= 0) return hipSuccess;
+    if ((nv == 2 || nv == 4) && tts_batch_width(m, nv) == nv) {        // the vectors share every pass over the words
+        const bool xl = tts_x_in_lds(m, nv);
+        hipError_t e = nv == 4 ? (xl ? launch_tts_nv2<4, true>(m, x, bias, y, alpha, beta, stream) : launch_tts_nv2<4, false>(m, x, bias, y, alpha, beta, stream))
+                               : (xl ? launch_tts_nv2<2, true>(m, x, bias, y, alpha, beta, stream) : launch_tts_nv2<2, false>(m, x, bias, y, alpha, beta, stream));
+        if (e != hipSuccess) return e;
+        if (m.n_fix > 0)
+            hipLaunchKernelGGL(spmv_fixup_short_kernel, dim3((m.n_fix + 255) / 256, nv), dim3(256), 0, stream, m.fix, m.n_fix, m.carry, y, alpha,
+                               (long long)m.n_carry, (long long)m.rows);
+        return hipGetLastError();
+    }
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_batched_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_batched_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        raised = true;
+    }
+    const size_t lds = tts_lds_bytes(m);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    if (beta != 0.0f) hipLaunchKernelGGL(spmv_tts_batched_kernel<true>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, bias, y, alpha, beta, nv);
+    else hipLaunchKernelGGL(spmv_tts_batched_kernel<false>, dim3((unsigned)m.n_tiles), dim3(m.threads), lds, stream, m, x, y, y, alpha, beta, nv);
+    if (m.n_fix > 0)      // rows cut into pieces: one fix-up launch for all vectors (grid.y = vector)
+        hipLaunchKernelGGL(spmv_fixup_short_kernel, dim3((m.n_fix + 255) / 256, nv), dim3(256), 0, stream, m.fix, m.n_fix, m.carry, y, alpha,
+                           (long long)m.n_carry, (long long)m.rows);
     return hipGetLastError();
 }
 
@@ -1429,10 +1592,13 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
     static bool raised = false;
     if (!raised) {
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
         raised = true;
     }
     if (!item_parts) n_items = n;
+    const bool xlds = tts_x_in_lds(entries[0].m, 1);       // the launch's matrices gather x from the LDS (a class of their own)
     MultiPrefix px{};
     px.n = n_items;
     long long g = 0;
@@ -1446,7 +1612,8 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
         long long most = 0;
         for (int q = 0; q < parts; ++q, ++e) {
             most = std::max<long long>(most, entries[e].m.n_tiles);
-            lds = std::max(lds, tts_lds_bytes(entries[e].m));
+            lds = std::max(lds, xlds ? tts_nv_lds_bytes(entries[e].m, 1, true) : tts_lds_bytes(entries[e].m));
+            if (tts_x_in_lds(entries[e].m, 1) != xlds) return hipErrorInvalidValue;      // (one class per launch: hispmv_abi.cpp)
         }
         if (parts == 1) g += most;
         else { const int per = 8 / parts; g += 8 * ((most + per - 1) / per); }
@@ -1454,7 +1621,10 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
     if (e != n) return hipErrorInvalidValue;
     px.begin[n_items] = g;
     if (g > 0x7fffffffLL || lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-    if (g > 0) hipLaunchKernelGGL(spmv_tts_multi_kernel, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
+    for (int i = 1; i < n; ++i) if (entries[i].m.zero_fill != entries[0].m.zero_fill || entries[i].m.threads != entries[0].m.threads) return hipErrorInvalidValue;
+    if (g > 0 && xlds) hipLaunchKernelGGL((spmv_tts_multi_kernel<false, true>), dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
+    else if (g > 0 && entries[0].m.zero_fill) hipLaunchKernelGGL(spmv_tts_multi_kernel<true>, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
+    else if (g > 0) hipLaunchKernelGGL(spmv_tts_multi_kernel<false>, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     return hipGetLastError();
 }
 
@@ -1613,7 +1783,9 @@ hipError_t graph_set_alpha(hipGraphExec_t exec, hipGraph_t graph, float alpha) {
         hipKernelNodeParams p{};
         if ((e = hipGraphKernelNodeGetParams(nodes[i], &p)) != hipSuccess) return e;
         int idx, n_args;
-        if (p.func == (void*)spmv_slices_multi_kernel || p.func == (void*)spmv_tts_multi_kernel || p.func == (void*)gemv_rows_multi_kernel ||
+        if (p.func == (void*)spmv_slices_multi_kernel || p.func == (void*)spmv_tts_multi_kernel<false> || p.func == (void*)spmv_tts_multi_kernel<true> ||
+            p.func == (void*)spmv_tts_multi_kernel<false, true> ||
+            p.func == (void*)gemv_rows_multi_kernel ||
             p.func == (void*)spmv_fixup_multi_kernel) { idx = 2; n_args = 3; }
         else if (p.func == (void*)spmv_fixup_long_kernel) { idx = 4; n_args = 7; }
         else if (p.func == (void*)spmv_tail_multi_kernel) { idx = 4; n_args = 5; }

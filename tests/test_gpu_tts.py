@@ -26,6 +26,10 @@ def make(case, rng):
     elif case == "wide_columns_few_rows":     # slices cut by the 16-bit column offset
         rows, cols, nnz = 40, 3000000, 120000
         r = rng.integers(0, rows, nnz); c = rng.integers(0, cols, nnz)
+    elif case == "short_wide_layer":          # x <= 256 KiB: 6 K-element tiles, four vectors share every pass of `linear`; a row cut into pieces
+        rows, cols, nnz = 300, 6000, 500000
+        r = rng.integers(0, rows, nnz); r[:200000] = 7
+        c = rng.integers(0, cols, nnz)
     elif case == "banded_jitter":
         rows = cols = 150000
         r = np.repeat(np.arange(rows), 6); nnz = r.size
@@ -37,7 +41,7 @@ def make(case, rng):
     return rows, cols, r.astype(np.int32), c.astype(np.int32), v
 
 
-CASES = [(c, "standard") for c in ("uniform_short_rows", "empty_and_heavy_rows", "wide_columns_few_rows", "banded_jitter", "duplicates")] + \
+CASES = [(c, "standard") for c in ("uniform_short_rows", "empty_and_heavy_rows", "wide_columns_few_rows", "banded_jitter", "duplicates", "short_wide_layer")] + \
         [(c, g) for g in ("tall", "paired") for c in ("uniform_short_rows", "empty_and_heavy_rows", "duplicates")]
 
 
@@ -61,7 +65,7 @@ def test_tile_stream_matches_its_model_and_the_fp64_truth(case, geometry, monkey
     assert info["format"] == 1 and info["group_slices"] == {"standard": 28, "tall": 23, "paired": 11}[geometry]
     assert info["col_tiles"] == (1 if geometry == "standard" else 2)
     if geometry == "standard":
-        assert info["n_split_rows"] == (2 if case == "empty_and_heavy_rows" else 0)      # rows cut into pieces (carry tiles + fix-up)
+        assert info["n_split_rows"] == {"empty_and_heavy_rows": 2, "short_wide_layer": 1}.get(case, 0)      # rows cut into pieces (carry tiles + fix-up)
     P = prep_from_coo(r, c, v, rows, cols, tts=(0, {13: 1, 28: 0, 23: "tall", 11: "paired"}[info["group_slices"]]))     # the geometry the loader chose
     rp = P.row_ptr.astype(np.int32)
     h.select_matrix(idx)
@@ -73,10 +77,12 @@ def test_tile_stream_matches_its_model_and_the_fp64_truth(case, geometry, monkey
             h.run_kernel(x, b, y, alpha, beta)
             assert bwd_err(y, y64, mag) < TOL
             assert np.array_equal(y.view(np.uint32), ye.view(np.uint32)), (case, alpha, beta)
-    # multi-vector linear: one launch per vector, each with the bits of a single call
-    X = np.concatenate([x, (x * np.float32(0.5)).astype(np.float32), x[::-1].copy()])
+    # multi-vector linear: several vectors per launch (small tiles: 4 / 2 vectors share every pass over the words; else one after
+    # the other inside the launch), each with the bits of a single call
+    X = np.concatenate([x, (x * np.float32(0.5)).astype(np.float32), x[::-1].copy(), (x + np.float32(0.25)).astype(np.float32),
+                        (x * np.float32(-1.5)).astype(np.float32), np.roll(x, 17), (x * x).astype(np.float32)])
     out = h.linear(idx, X, b)
-    for k in range(3):
+    for k in range(7):
         yk = oracle.emu_tts(P.tts, X[k * cols:(k + 1) * cols], b, 1.0, 1.0, rows)
         assert np.array_equal(out[k * rows:(k + 1) * rows].view(np.uint32), yk.view(np.uint32))
     # batch entry point, next to a slice-stream matrix and a dense handle
