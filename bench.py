@@ -306,6 +306,32 @@ class Runner:
             def step():
                 fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
                 exch.run(mats, ALPHA, prepared=True)
+            # The rank's whole step -- batch launches, tail pack, the RCCL all_gather, tail apply -- as ONE graph launch: the
+            # collective runs on the process group's own stream, and eagerly every step pays two stream hand-offs around it
+            # (one rank, RCCL: 0.325 ms per step against 0.300 without the exchange).  Captured with torch.cuda.graph (RCCL
+            # kernels are capturable; the library sees the capture and issues plain launches); any failure keeps the eager step.
+            if os.environ.get("HISPMV_BENCH_STEP_GRAPH", "1") == "1" and exch.send.is_cuda and exch.dist.get_backend() == "nccl":
+                torch = self.torch
+                try:
+                    for _ in range(3):
+                        step()
+                    self.fence()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.stream):
+                        step()
+                    self.fence()
+                    g.replay()
+                    self.fence()
+                    self.step_graph = g                 # (keeps the graph alive)
+                    self.step_mode = "graph"
+                    return g.replay
+                except Exception as ex:                 # capture refused: eager step
+                    sys.stderr.write(f"bench.py: step graph not used ({type(ex).__name__}: {str(ex)[:200]})\n")
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:
+                        pass
+                    self.step_mode = "eager"
         else:
             def step():
                 fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
@@ -323,6 +349,15 @@ class Runner:
         caller's --warmup.  Steps are issued for `seconds` of wall time (bounded by max_steps), then the device drains;
         reported as preheat_ms, outside every timed region."""
         t0 = time.perf_counter()
+        if seconds <= 0:
+            return 0.0
+        if self.dist_on:
+            # a step contains a collective: every rank must issue the SAME number of steps -- a fixed count instead of a
+            # wall-time bound (about 0.2-0.3 s of the 20-matrix step)
+            for _ in range(800):
+                step()
+            self.fence()
+            return (time.perf_counter() - t0) * 1e3
         n = 0
         while time.perf_counter() - t0 < seconds and n < max_steps:
             for _ in range(20):
@@ -340,6 +375,9 @@ class Runner:
         with the chain rule of hispmv_amd.dist.chain_weights.  -> (worst error over ranks, rows checked over ranks)."""
         import scipy.sparse as sp
         torch = self.torch
+        for m in mats:                               # the step must WRITE every y: results left over from earlier steps do not count
+            m["y"].fill_(float("nan"))
+        self.fence()
         step()
         self.fence()
         worst, n_rows, skipped = 0.0, 0, 0
@@ -707,7 +745,7 @@ def main():
                        "sources": sorted(set(m["source"].split(":")[0] for m in mats)), "standin": args.standin,
                        "alpha": ALPHA, "beta": BETA, "launch": args.launch, "streams": n_streams,
                        "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
-            "ranks_seen": ranks_seen, "backend": backend,
+            "ranks_seen": ranks_seen, "backend": backend, "rank_step": getattr(R, "step_mode", "eager" if dist_on else "library graph"),
             "passes_over_set": args.warmup + args.steps + (2 if args.launch == "streams" else 0),
             "hbm_gbs_algorithmic": round(total_bytes / t_wall / 1e9, 1),
             "hbm_pct_of_peak": round(100 * total_bytes / t_wall / 1e9 / (HBM_PEAK_GBS * world), 2),

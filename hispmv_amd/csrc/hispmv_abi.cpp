@@ -1369,7 +1369,12 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     // kernels' attributes) and replayed from then on: the set's step 0.315-0.320 -> 0.309-0.310 ms -- the fork/join events
     // of the two streams become graph edges.  HISPMV_BATCH_GRAPH=0 switches it off; a stream that is being captured by the
     // caller, or a capture the runtime refuses, falls back to plain launches.
-    if (c->batch_graphs && lanes > 1) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
+    // (a stream the CALLER is capturing takes plain launches: they become nodes of the caller's graph; replaying the library's
+    // own graph into a capture recorded nothing on this runtime)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool caller_captures = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    if (c->batch_graphs && lanes > 1 && !caller_captures) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
         auto drop_graph = [&]() {
             if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
             if (plan->graph_src) { (void)hipGraphDestroy(plan->graph_src); plan->graph_src = nullptr; }

@@ -123,6 +123,22 @@ def run_set(torch, mats, label):
                     float(a_k), BETA, mkl=False)
             st2 = h.batch_graph_stats()
             assert st2["instantiations"] == 1 and st2["alpha_updates"] == st["alpha_updates"] + 6, st2
+            # the CALLER captures the call into a graph of its own (bench.py --gpus N captures a rank's whole step): the library
+            # must issue plain launches into the capture -- replaying its own graph there recorded nothing -- and the replay
+            # must write every y
+            side = torch.cuda.Stream(device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                h.spmv_device_batch(batch, ALPHA, BETA, side.cuda_stream)
+            for m in mats:
+                m["dy"].fill_(float("nan"))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for m in sorted(mats, key=lambda q: -len(q["va"]))[:4]:
+                check_y(f'{label}:{m["name"]}:batch:caller_graph', m["dy"].cpu().numpy(), m["rp"], m["ci"], m["va"], m["cols"], m["x"], m["b"], ALPHA, BETA, mkl=False)
+            assert h.batch_graph_stats()["instantiations"] == 1
+            del g
             for m in mats:
                 m["dy"].fill_(float("nan"))
             torch.cuda.synchronize()

@@ -24,6 +24,12 @@ for w in ("dense", "model", "powerlaw"):
         shutil.copy(files[-1], prof / f"{tag}_{w}_kernel_stats.csv")
 if (out / "parity_report.json").exists():
     shutil.copy(out / "parity_report.json", prof / f"{tag}_parity_report.json")
+drv = out / f"{tag}m" / "bench_driver_style.log"
+if drv.exists():           # the line of `python bench.py --gpus 1 --steps 20 --warmup 5` (what the driver runs at round end)
+    dl = [q for q in drv.read_text().splitlines() if q.startswith("{")]
+    if dl:
+        json.loads(dl[-1])
+        (prof / f"{tag}_bench_line_driver_style.json").write_text(dl[-1] + "\n")
 details = out / f"{tag}m" / "details_default.json"
 line = (out / f"{tag}m" / "bench_default.log").read_text().strip().splitlines()[-1]
 json.loads(line)
@@ -37,11 +43,17 @@ traffic = json.loads((prof / f"{tag}_traffic.json").read_text())
 alg = sum(M.algorithmic_bytes(r["rows"], r["rows"], r["nnz"]) for r in rows)
 cb, su, ss, rf = s["cpu_baseline"], s["standin_uniform"], s["strong_scaling"], s["roofline"]
 hbm = traffic.get("hbm_bytes_per_step")
+drv_note = ""
+if (prof / f"{tag}_bench_line_driver_style.json").exists():
+    dd = json.loads((prof / f"{tag}_bench_line_driver_style.json").read_text())
+    drv_note = (f" Driver-style (`--gpus 1 --steps 20 --warmup 5`, `profiles/{tag}_bench_line_driver_style.json`): {dd['value']} GFLOP/s, "
+                f"{dd['ms_per_step']} ms per step, frac {dd['roofline']['frac']} (pessimistic family {dd['standin_uniform']['roofline_frac']}); "
+                f"both lines carry `y_checked: {str(dd['y_checked']).lower()}` (max backward error {dd['y_check']['max_backward_error']:.2e} over {dd['y_check']['rows_checked']} rows).")
 lines = [
     f"`python bench.py` (defaults: {s['steps']} steps, {s['warmup']} warm-up; `profiles/{tag}_bench_line.json`, "
     f"`profiles/{tag}_bench_details.json`): **{s['value']} GFLOP/s** over the set, {s['ms_per_step']} ms per step, "
     f"{s['hbm_gbs_algorithmic']} GB/s algorithmic = **{s['hbm_pct_of_peak']} % of the 8 TB/s peak**; `roofline.achieved` "
-    f"{rf['achieved']} GB/s (HIP events), `frac` {rf['frac']}.",
+    f"{rf['achieved']} GB/s (HIP events), `frac` {rf['frac']}." + drv_note,
     f"The same step with the pessimistic stand-in family (`standin_uniform`): {su['value']} GFLOP/s, {su['ms_per_step']} ms, "
     f"frac {su['roofline_frac']}. Six largest matrices alone (`strong_scaling` at n_gpus = 1): {ss['value']} GFLOP/s, "
     f"{ss['ms_per_step']} ms per step.",

@@ -8,6 +8,7 @@ doubled; WRITE_SIZE is exact for dword-per-lane stores.  Collected in separate -
 import csv
 import glob
 import json
+import re
 import sys
 from collections import defaultdict
 from pathlib import Path
@@ -74,7 +75,7 @@ if single:
     # the timed steps are the last 30 of 230: keep the last 30 launches of every (kernel, workgroup size)
     per = defaultdict(list)
     for r in rows_k:
-        per[(r["Kernel_Name"].split("(")[0].replace("hispmv::", ""), int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        per[(re.sub(r"<.*", "", r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hispmv::", "")).strip(), int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     table = []
     for (name, wg), d in sorted(per.items(), key=lambda kv: -sum(kv[1][-30:])):
         tail = d[-30:]
