@@ -149,3 +149,39 @@ def test_stacked_block_shards_cut_rows_and_reassemble():
         assert np.isnan(Y[s.row_begin:s.row_begin + n]).all()
         Y[s.row_begin:s.row_begin + n] = y[:n]
     assert not np.isnan(Y).any() and bwd_err(Y, y64, mag) < 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_virtual_ranks_loopback_world(world):
+    """hispmv_amd.dist.LoopbackWorld: `world` virtual ranks in ONE process (what tests/test_gpu_dist_full.py runs at world 8 on
+    the one-GPU box: the card takes at most 6 processes) -- the same shards, pack / apply halves and chain weights as the
+    process-per-rank path, the all_gather a concatenation.  Here on CPU tensors, the local SpMV played by the oracle."""
+    from hispmv_amd.dist import LoopbackWorld
+    alpha, beta = 0.85, -2.06
+    mats = make_matrices()
+    per_rank = []
+    for rank in range(world):
+        local = []
+        for m in mats:
+            sh = shard_csr(m["rp"], m["ci"], m["va"], world, rank)
+            local.append(dict(shard=sh, y=torch.zeros(sh.n_rows, dtype=torch.float32)))
+        per_rank.append(local)
+    lw = LoopbackWorld(per_rank, torch.device("cpu"))
+    for _ in range(2):                        # the second step must not double count
+        for local in per_rank:
+            for ent, m in zip(local, mats):
+                sh = ent["shard"]
+                if sh.n_rows:
+                    ent["y"].copy_(torch.from_numpy(oracle.cpu_spmv(sh.row_ptr, sh.col_idx, sh.values, m["x"], sh.local_bias(m["b"]), alpha, beta, 1)))
+        lw.exchange()
+    for i, m in enumerate(mats):
+        y = np.full(m["rows"], np.nan, np.float32)
+        cover = np.zeros(m["rows"], int)
+        for local in per_rank:
+            sh = local[i]["shard"]
+            n_own = sh.n_rows - (1 if sh.tail_open else 0)
+            y[sh.row_begin:sh.row_begin + n_own] = local[i]["y"][:n_own].numpy()
+            cover[sh.row_begin:sh.row_begin + n_own] += 1
+        assert (cover == 1).all(), "every row has exactly one owner"
+        y64, mag = oracle.spmv_f64(m["rp"], m["ci"], m["va"], m["x"], m["b"], alpha, beta)
+        assert bwd_err(y, y64, mag) < 1e-5

@@ -10,6 +10,7 @@ TAG=${1:-r3}; WHAT=${2:-tests}
 O=gpurun_out/${TAG}m; mkdir -p $O gpurun_out/prof_${TAG}_dense gpurun_out/prof_${TAG}_model gpurun_out/prof_${TAG}_powerlaw
 if [ "$WHAT" = tests ]; then
   timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_all.log 2>&1; echo "pytest all rc=$?"; tail -14 $O/pytest_all.log
+  python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
   timeout -k 10 400 python3 bench.py --details $O/details_default.json > $O/bench_default.log 2>&1; echo "default rc=$?"; tail -1 $O/bench_default.log | cut -c1-400
   timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.log 2>&1; echo "driver-style rc=$?"; tail -1 $O/bench_driver_style.log | cut -c1-400
 else
