@@ -48,6 +48,7 @@ SIGNATURES = {
     "hispmv_prep_tts_array": (C.c_void_p, [_p, C.c_int]),
     "hispmv_prep_tts_pieces": (C.c_int, [_p, C.POINTER(C.c_int64)]),
     "hispmv_version": (C.c_char_p, []),
+    "hispmv_host_threads": (C.c_int, []),
     "hispmv_free_failures": (C.c_int64, []),
     "hispmv_boundary_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "hispmv_boundary_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

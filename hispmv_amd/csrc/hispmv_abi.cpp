@@ -603,6 +603,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
                              int urams, int fp_acc_latency, int dense, int pre_acc, int row_dist) {
     if (!out) return fail(nullptr, HISPMV_EINVAL, "out is NULL");
     *out = nullptr;
+    configure_host_threads();       // OpenMP threads of the preprocessor = the CPUs this process may use (cgroup quota)
     // same argument checks as fpga_handle.cpp:51-52,70-71
     if (device_id < 0) return fail(nullptr, HISPMV_EINVAL, "Device ID must be a non-negative integer.");
     if (!xclbin_path || !*xclbin_path) return fail(nullptr, HISPMV_EINVAL, "XCLBIN path is empty.");
@@ -1473,9 +1474,12 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
 // ---- host-only preprocessor access ---------------------------------------------------------------
 HISPMV_API const char* hispmv_prep_last_error(void) { return g_prep_err.c_str(); }
 
+HISPMV_API int hispmv_host_threads(void) { return configure_host_threads(); }
+
 HISPMV_API int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* r, const int32_t* cl, const float* v,
                                     int64_t nnz, int32_t rows, int32_t cols) {
     if (!out) return HISPMV_EINVAL;
+    configure_host_threads();
     *out = nullptr;
     if (rows <= 0 || cols <= 0 || nnz < 0) { g_prep_err = "bad sparse matrix arguments"; return HISPMV_EINVAL; }
     try {
@@ -1508,6 +1512,7 @@ HISPMV_API int hispmv_prep_from_coo_device(hispmv_prep** out, int device_id, con
 }
 
 HISPMV_API int hispmv_prep_from_mtx(hispmv_prep** out, const char* path, int flavor) {
+    configure_host_threads();
     if (!out) return HISPMV_EINVAL;
     *out = nullptr;
     if (!path || (flavor != 0 && flavor != 1)) { g_prep_err = "bad arguments"; return HISPMV_EINVAL; }

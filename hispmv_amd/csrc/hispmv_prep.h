@@ -67,6 +67,10 @@ enum MtxFlavor {
     kFlavorCpu = 1       // cpu/ driver semantics (helper_functions.cpp:91-146)
 };
 
+// Sets (once) the OpenMP thread count of the host preprocessor to the CPUs the process may use (cgroup cpu.max quota);
+// returns it.  Called by every entry point that preprocesses.
+int configure_host_threads();
+
 // MatrixMarket coordinate reader.  Throws std::runtime_error with the reference's
 // failure classes (not a MatrixMarket file / unsupported type) -- spmv-helper.cpp:50-71.
 Coo read_mtx(const std::string& path, MtxFlavor flavor);

@@ -230,6 +230,10 @@ const void* hispmv_prep_tts_array(const hispmv_prep* p, int which);
  * hispmv_prep_tts_array = {row, first carry, carries, 0} per row cut (int32 x 4). */
 int hispmv_prep_tts_pieces(const hispmv_prep* p, int64_t counts[2]);
 
+/* OpenMP threads the host preprocessor uses: the CPUs this process may use (cgroup cpu.max quota, e.g. 16 of the 256 a GPU
+ * box shows), set once at the first call of the library unless OMP_NUM_THREADS is given. */
+int hispmv_host_threads(void);
+
 /* Library identification: "hispmv-amd <version> gfx950". */
 const char* hispmv_version(void);
 

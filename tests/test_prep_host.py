@@ -95,7 +95,7 @@ def test_stream_decodes_to_mkl_result(name, golden):
     y64, mag = oracle.spmv_f64(g["ref_row_ptr"], g["ref_col_idx"], g["ref_vals"], x, y0, ALPHA, BETA)
     assert bwd_err(y, y64, mag) < TOL
     # and directly against the MKL vector (both fp32): within 2*TOL of each other in the same scale
-    assert float(np.max(np.abs(y.astype(np.float64) - g["y_mkl"]) / mag)) < 2 * TOL
+    assert float(np.max(np.abs(y.astype(np.float64) - g["y_mkl"]) / mag)) < 3e-6          # measured envelope 1.4e-6
 
 
 def test_product_reader_keeps_last_line_without_newline(tmp_path):
@@ -337,3 +337,28 @@ def test_transposed_tile_stream_packer_and_its_model(shape):
     y = oracle.emu_tts(T, x, b, ALPHA, BETA, rows)
     y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, ALPHA, BETA)
     assert bwd_err(y, y64, mag) < TOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_flavours_agree_where_their_semantics_coincide(name):
+    """bench.py feeds real .mtx files through flavour 1 (the cpu/ reader, pinned bit-exact by the reference itself); flavour 0
+    (HiSpmvHandle::loadMtx, spmv-helper.cpp:34-136: parity unpinned) must give the SAME matrix on every file where the two
+    readers' rules coincide -- anything but skew-symmetric files (loadMtx mirrors them negated, :116-129; the cpu/ reader does
+    not, helper_functions.cpp:135) and files with explicit zeros (loadMtx drops value == 0, :105; the cpu/ reader drops the
+    bit pattern 0 only and keeps -0.0, :124).  On the others the difference is exactly that rule."""
+    path = GOLDEN / f"{name}.mtx"
+    lines = path.read_text().splitlines()
+    header = lines[0].lower().split()
+    skew = "skew-symmetric" in header
+    pattern = "pattern" in header
+    body = [ln.split() for ln in lines[1:] if ln and not ln.startswith("%")][1:]
+    zeros = (not pattern) and any(float(t[2]) == 0.0 for t in body if len(t) >= 3)
+    P0, P1 = prep_from_mtx(path, flavor=0), prep_from_mtx(path, flavor=1)
+    assert (P0.rows, P0.cols) == (P1.rows, P1.cols)
+    if not skew and not zeros:
+        assert np.array_equal(P0.row_ptr, P1.row_ptr) and np.array_equal(P0.col_idx, P1.col_idx)
+        assert np.array_equal(P0.values.view(np.uint32), P1.values.view(np.uint32))
+    elif skew:
+        assert P0.nnz > P1.nnz           # the mirrored (negated) off-diagonal entries
+    else:
+        assert P0.nnz <= P1.nnz          # loadMtx drops every value == 0, the cpu/ reader only the bit pattern 0
