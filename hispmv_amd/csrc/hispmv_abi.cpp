@@ -344,7 +344,9 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096;
     const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
     if (candidate && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
-        TtsStream ts = build_tts(csr);
+        TtsGeometry g0;
+        g0.zero_fill = c->tts_geometry == 4;        // HISPMV_TTS_GEOMETRY=zerofill: the standard sizes, no filler words (experiment)
+        TtsStream ts = build_tts(csr, 0, g0);
         if (ts.lines_per_gather <= 8.0 && std::getenv("HISPMV_TTS_SMALL")) {
             // experiment (off by default: measured slower): cheap gathers -> the half-LDS geometry, two workgroups per CU
             TtsGeometry small;
@@ -489,7 +491,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
 
 int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
                   float alpha, float beta, hipStream_t s, bool fixup_only = false) {
-    if (!m.dense && m.parts.size() > 1 && m.index >= 0) {
+    if (!m.dense && (m.parts.size() > 1 || (m.format == 1 && m.parts[0].tdev.zero_fill)) && m.index >= 0) {
         // column tiles: all of them in ONE grid (+ one fix-up, one merge launch) through the batch machinery -- launched
         // one after the other each tile had the chip to itself for half the work (mouse_gene 48 -> 40 us)
         const int32_t idx = m.index;
@@ -649,7 +651,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(fork)");
     if (const char* env = std::getenv("HISPMV_FORMAT"))
         c->format_mode = !std::strcmp(env, "slices") ? 0 : !std::strcmp(env, "tts") ? 1 : 2;
-    if (const char* env_g = std::getenv("HISPMV_TTS_GEOMETRY")) c->tts_geometry = !std::strcmp(env_g, "standard") ? 0 : !std::strcmp(env_g, "tall") ? 1 : !std::strcmp(env_g, "paired") ? 3 : 2;
+    if (const char* env_g = std::getenv("HISPMV_TTS_GEOMETRY")) c->tts_geometry = !std::strcmp(env_g, "standard") ? 0 : !std::strcmp(env_g, "tall") ? 1 : !std::strcmp(env_g, "paired") ? 3 : !std::strcmp(env_g, "zerofill") ? 4 : 2;
     if (const char* env = std::getenv("HISPMV_PREP"))
         c->prep_mode = !std::strcmp(env, "host") ? 0 : !std::strcmp(env, "device") ? 1 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1559,7 +1561,8 @@ HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, 
     try {
         TtsGeometry geo;
         if (small_geometry == 1) { geo.max_slots = kTtsSmallSlots; geo.max_rows = kTtsSmallRows; geo.tiles_wanted = 512; }
-        if (small_geometry >= 2) {         // 2 + q / 4 + q: column part q of the tall / paired geometry, as the loader builds it for a 256-CU device
+        if (small_geometry == 6) geo.zero_fill = true;      // the standard sizes without filler words (HISPMV_TTS_GEOMETRY=zerofill)
+        if (small_geometry >= 2 && small_geometry < 6) {         // 2 + q / 4 + q: column part q of the tall / paired geometry, as the loader builds it for a 256-CU device
             const bool paired = small_geometry >= 4;
             const int q = small_geometry - (paired ? 4 : 2);
             if (q >= kTtsTallParts) { g_prep_err = "no such column part"; return HISPMV_EINVAL; }

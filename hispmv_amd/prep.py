@@ -40,7 +40,7 @@ def _collect_tts(p, target, geometry: int = 0):
         target, geometry = target
     if geometry in ("tall", "paired"):
         return [_collect_tts(p, target, (2 if geometry == "tall" else 4) + q) for q in range(2)]
-    geometry = int(geometry)
+    geometry = 6 if geometry == "zerofill" else int(geometry)
     cnt = (C.c_int64 * 8)()
     lpg = C.c_double()
     if lib.hispmv_prep_build_tts(p, int(target), geometry, cnt, C.byref(lpg)) != HISPMV_OK:
