@@ -60,8 +60,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", choices=["set", "powerlaw", "dense", "model"], default="set")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="what the main line measures when --gpus > 1")
-    ap.add_argument("--strong-gb", type=str, default="", help="comma-separated sizes (GB of stream) of synthetic row-shardable "
-                    "banded matrices added to the strong-scaling set, e.g. 2,4,8 (SURVEY.md 8d C5); generated rank-locally")
+    ap.add_argument("--strong-gb", type=str, default="2", help="comma-separated sizes (GB of stream) of synthetic row-shardable "
+                    "banded matrices added to the strong-scaling set, e.g. 2,4,8 (SURVEY.md 8d C5); generated rank-locally as 64 stacked "
+                    "blocks.  Default 2: with the six SuiteSparse-size matrices alone a rank of 8 has ~30 us of kernels per step, less "
+                    "than the launch and exchange latency around them; empty = only the six")
     ap.add_argument("--matrices", type=str, default="", help="comma-separated subset of the set (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed steps before the warm-up (clock ramp; 0 = none)")
@@ -219,6 +221,14 @@ def load_strong(names, rank, world, gb_sizes):
         sh = shard_csr(m["rp"], m["ci"], m["va"], world, rank)
         out.append(dict(name=m["name"], source=m["source"], rows=sh.n_rows, cols=m["cols"], nnz=int(sh.row_ptr[-1]), rp=sh.row_ptr,
                         ci=sh.col_idx, va=sh.values, shard=sh, x_touch=m["cols"] // world, full_rows=m["rows"], full_nnz=m["nnz"]))
+    return out + load_strong_gb(rank, world, gb_sizes)
+
+
+def load_strong_gb(rank, world, gb_sizes):
+    """The synthetic row-shardable banded matrices of SURVEY.md 8d C5: `gb` GB of stream as 64 stacked row blocks; a rank
+    generates (and holds) only its own blocks -- row-aligned shards, nothing is cut."""
+    from hispmv_amd import matrices as M
+    out = []
     for gb in gb_sizes:
         blocks, per_row, band = 64, 50, 20000
         nnz_b = int(gb * 1e9 / 8 / blocks)
@@ -657,7 +667,7 @@ def main():
             # strong scaling of the six largest matrices: the SAME matrices at every N, nnz-split over the ranks
             smats = [m for m in mats if m["name"] in STRONG_SET] if world == 1 else load_strong(STRONG_SET, rank, world, gb_sizes)
             if world == 1 and gb_sizes:
-                extra_gb = [m for m in load_strong([], rank, world, gb_sizes)]
+                extra_gb = load_strong_gb(rank, world, gb_sizes)
                 R.add(extra_gb)
                 smats = smats + extra_gb
             if world > 1:
@@ -669,11 +679,13 @@ def main():
             sstep = R.batch_step(smats, sexch)
             R.preheat(sstep, min(args.preheat, 0.15))
             tw, td = R.time_steps(sstep, args.steps, args.warmup)
+            s_err, s_rows, _ = (R.verify(smats, sstep) if not args.no_verify else (None, 0, 0))
             fl = sum(M.flops(m.get("full_rows", m["rows"]), m.get("full_nnz", m["nnz"])) for m in smats)
             by = sum(M.algorithmic_bytes(m.get("full_rows", m["rows"]), m["cols"], m.get("full_nnz", m["nnz"])) for m in smats)
             extras["strong_scaling"] = {"matrices": [m["name"] for m in smats], "n_gpus": world, "value": round(fl * args.steps / tw / 1e9, 2),
                                         "unit": "GFLOP/s", "ms_per_step": round(tw / args.steps * 1e3, 4),
                                         "hbm_gbs_algorithmic": round(by * args.steps / tw / 1e9, 1), "scaling": "strong",
+                                        "y_checked": bool(s_err is not None and s_err < 1e-5 and s_rows > 0), "y_max_backward_error": s_err,
                                         "note": "whole-job rate of the same matrices nnz-split over n_gpus ranks (shard_csr); speed-up = value / the n_gpus = 1 value"}
 
     if args.workload == "model" and rank == 0 and not args.no_extras:
