@@ -2,6 +2,7 @@
 #include "hispmv_tts.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -124,7 +125,8 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     // (the floor keeps enough elements per tile for the lanes of a gather to share lines of x; when x is at most 256 KiB --
     // a wide, short layer of apps/model_test.py: 1024 x 8192 -- its lines stay in L1 / L2 whatever the tile, and a tile per
     // CU matters more: 6 K elements instead of 24 K, 256 tiles instead of 87 for that layer)
-    const int64_t floor_elems = m.cols <= 64 * 1024 ? 6 * kTtsChunk : 24 * kTtsChunk;
+    int64_t floor_elems = m.cols <= 64 * 1024 ? 6 * kTtsChunk : 24 * kTtsChunk;
+    if (const char* env = std::getenv("HISPMV_TTS_FLOOR")) floor_elems = std::max<int64_t>(1024, std::atoll(env));     // experiments
     int64_t target = target_tile_elems > 0 ? target_tile_elems : std::max<int64_t>(total / geo.tiles_wanted, std::min<int64_t>(floor_elems, geo.max_slots));
     struct Range { int32_t r0, r1; int64_t k0, k1; int32_t carry; };     // k0 >= 0: the piece [k0, k1) of row r0; carry >= 0: carry tile
     std::vector<Range> ranges;
