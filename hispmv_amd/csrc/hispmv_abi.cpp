@@ -84,7 +84,7 @@ struct hispmv_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int batch_streams = 2;
     int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first
-    bool batch_lanes_lpt = false; // HISPMV_BATCH_LANES=lpt
+    bool batch_lanes_heavy_first = true;   // HISPMV_BATCH_LANES=rr: plain round-robin lanes
     bool batch_graphs = true;    // HISPMV_BATCH_GRAPH=0: no HIP graph replay of batch calls
     // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
     // the three model_test layers: 49.9 us on one stream, 63.1 on two; the 20-matrix set: 353 -> 344 us with two)
@@ -642,7 +642,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     if (const char* env = std::getenv("HISPMV_BATCH_GRAPH")) c->batch_graphs = std::atoi(env) != 0;
     if (const char* env = std::getenv("HISPMV_BATCH_ORDER")) c->batch_order = !std::strcmp(env, "small_first") ? 1 : 0;
-    if (const char* env = std::getenv("HISPMV_BATCH_LANES")) c->batch_lanes_lpt = !std::strcmp(env, "lpt");
+    if (const char* env = std::getenv("HISPMV_BATCH_LANES")) c->batch_lanes_heavy_first = std::strcmp(env, "rr") != 0;
     if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) { c->batch_streams = std::max(1, std::min(3, std::atoi(env))); c->batch_streams_min_bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate(side)");
@@ -1091,6 +1091,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             const bool pinned = pin && (m.parts.size() == 2 || m.parts.size() == 4);
             for (size_t t = 0; t < m.parts.size(); ++t) {
                 l.tts.push_back(TtsEntry{m.parts[t].tdev, d_x[i], t == 0 ? bias[i] : nullptr, out_of(Ref{i, t}), t == 0 ? beta : 0.0f, 0});
+                if (t == 0) l.weight += m.n_slices * (int64_t)kWideSliceBytes * 5 / 2;
                 if (!pinned) l.item_tiles.push_back(1);
             }
             if (pinned) l.item_tiles.push_back((uint8_t)m.parts.size());
@@ -1166,36 +1167,35 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         if (!m.dense && m.format == 1)
             for (size_t t = 0; t < m.parts.size(); ++t) if (m.parts[t].tdev.n_fix > 0) fixrefs.push_back(Ref{i, t});
     }
-    // Lanes of the main launches: round-robin in launch order (default), or HISPMV_BATCH_LANES=lpt: longest-processing-time-
-    // first on the device bytes of their matrices with the heaviest lane on the CALLER'S stream, so that the tail launch
-    // follows the last-finishing main launch in stream order instead of behind an event of another stream.  Measured on the
-    // benchmark step (profiles/r3_experiments/step_structure.json): with plain launches the lpt lanes bring the tail from
-    // 11-12 us behind the last main kernel to 6 us, but the step does not get shorter (0.298-0.299 ms either way: the tile
-    // streams start behind the slice grid and run longer); replayed as a graph the runtime maps the branches to its own
-    // queues whatever the capture streams were, and round-robin order measures 0.298 against 0.302-0.303.
+    // Lanes of the main launches: round-robin in launch order, and the lane with the most (time-weighted) bytes is the CALLER'S
+    // stream with its launches ENQUEUED FIRST (HISPMV_BATCH_LANES=rr: plain round-robin), so that the tail launch follows the
+    // last-finishing chain on the same queue instead of behind a cross-queue dependency.  Replayed as a graph the runtime
+    // keeps the chain of the FIRST captured root on the launch stream's queue: with the 1024-thread slice grid captured first
+    // (the structured set, where it finishes last) the tail starts 6.7 us behind its end instead of 12 (kernel timelines in
+    // profiles/r3_experiments/step_structure.json): 0.288-0.294 against 0.291-0.299 ms per step; in the pessimistic family
+    // the tile streams are the heavier chain and the order stays what it was.  (Measured and dropped: longest-processing-time
+    // assignment -- the 256-thread grid then follows the 1024-thread one and the pessimistic family loses 1-4 %; the heavy
+    // lane on the caller's stream but captured second: 0.302-0.303.)
     {
         plan.lanes = plan.stream_bytes >= c->batch_streams_min_bytes ? c->batch_streams : 1;
         std::vector<hispmv_ctx::BatchLaunch*> mains;
         for (auto& l : plan.launches) {
             if (l.kind == 0) for (const SpmvDeviceMatrix* d : l.parts) l.weight += d->n_slices * (int64_t)kWideSliceBytes;
-            if (l.kind == 3) for (const TtsEntry& e : l.tts) l.weight += (int64_t)e.m.n_tiles * 128 * 1024;
+            // (a tile stream runs at ~2.5 TB/s against ~6.5 for a slice stream: its bytes count 2.5-fold; set when the entries were made)
             if (l.kind == 4) for (const GemvEntry& e : l.gemv) l.weight += 4 * (int64_t)e.rows * e.cols;
             mains.push_back(&l);
         }
         plan.lanes = std::max(1, std::min<int>(plan.lanes, (int)mains.size()));
-        std::vector<hispmv_ctx::BatchLaunch*> by_weight = mains;
-        std::stable_sort(by_weight.begin(), by_weight.end(), [](const hispmv_ctx::BatchLaunch* x, const hispmv_ctx::BatchLaunch* y) { return x->weight > y->weight; });
-        if (c->batch_lanes_lpt) {
+        // round-robin in launch order (tile streams, 1024-thread slices, 256-thread slices, ...) ...
+        int k = 0;
+        for (hispmv_ctx::BatchLaunch* l : mains) l->lane = k++ % plan.lanes;
+        if (c->batch_lanes_heavy_first && plan.lanes >= 2) {
+            // ... and the lane with the most (time-weighted) bytes becomes the caller's stream, its launches enqueued first
             std::vector<int64_t> load((size_t)plan.lanes, 0);
-            for (hispmv_ctx::BatchLaunch* l : by_weight) {
-                const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-                l->lane = k; load[(size_t)k] += l->weight;
-            }
+            for (hispmv_ctx::BatchLaunch* l : mains) load[(size_t)l->lane] += l->weight;
             const int heavy = (int)(std::max_element(load.begin(), load.end()) - load.begin());
             for (hispmv_ctx::BatchLaunch* l : mains) l->lane = l->lane == heavy ? 0 : l->lane == 0 ? heavy : l->lane;
-        } else {
-            int k = 0;
-            for (hispmv_ctx::BatchLaunch* l : mains) l->lane = k++ % plan.lanes;       // launch order: tile streams, 1024-thread slices, 256-thread slices
+            std::stable_sort(plan.launches.begin(), plan.launches.end(), [](const hispmv_ctx::BatchLaunch& x, const hispmv_ctx::BatchLaunch& y) { return x.lane < y.lane; });
         }
     }
     // The tail: ONE launch that finishes the cut rows and merges the partial vectors of column-tiled matrices (which then

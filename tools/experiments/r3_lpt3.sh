@@ -1,0 +1,10 @@
+#!/bin/bash
+out=gpurun_out/r3y; mkdir -p $out
+timeout -k 10 900 python3 -m pytest tests/test_gpu_bench_set.py tests/test_gpu_parity.py tests/test_gpu_tts.py -x -q > $out/pytest.log 2>&1; echo "pytest rc $?"; tail -2 $out/pytest.log
+run() { tag=$1; shift; env "$@" python3 bench.py --no-cpu-baseline --no-verify --steps 300 --warmup 100 --per-matrix-reps 0 > $out/$tag.log 2>&1
+  echo "$tag: $(grep -o '"ms_per_step": [0-9.]*\|"frac": [0-9.]*\|"roofline_frac": [0-9.]*' $out/$tag.log | tr '\n' ' ')"; }
+run lpt X=1
+run rr HISPMV_BATCH_LANES=rr
+run lpt_b X=1
+run rr_b HISPMV_BATCH_LANES=rr
+for w in model powerlaw dense; do python3 bench.py --workload $w --no-cpu-baseline --no-extras --per-matrix-reps 0 > $out/$w.log 2>&1; echo "$w: $(grep -o '"ms_per_step": [0-9.]*\|"frac": [0-9.]*' $out/$w.log | tr '\n' ' ')"; done

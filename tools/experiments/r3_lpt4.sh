@@ -1,0 +1,9 @@
+#!/bin/bash
+out=gpurun_out/r3z; mkdir -p $out
+run() { tag=$1; shift; env "$@" python3 bench.py --no-cpu-baseline --no-verify --steps 300 --warmup 100 --per-matrix-reps 0 > $out/$tag.log 2>&1
+  echo "$tag: $(grep -o '"ms_per_step": [0-9.]*\|"frac": [0-9.]*\|"roofline_frac": [0-9.]*' $out/$tag.log | tr '\n' ' ')"; }
+for r in 1 2; do
+run rr_$r HISPMV_BATCH_LANES=rr
+run sf_$r HISPMV_BATCH_LANES=slices_first
+run lpt_$r HISPMV_BATCH_LANES=lpt
+done
