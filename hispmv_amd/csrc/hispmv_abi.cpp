@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -280,7 +281,7 @@ void plan_part(Matrix::Part& p, int n_cus) {
 }
 void pack_part(Matrix::Part& p) {
     p.dstream = pack_device_stream(p.st, p.plan);
-    p.st.words = std::vector<uint64_t>();   // the device layout replaces the host words
+    p.st.words = WordVec();   // the device layout replaces the host words
 }
 void finish_part(Matrix::Part& p, int n_cus) { plan_part(p, n_cus); pack_part(p); }
 
@@ -288,11 +289,24 @@ void finish_part(Matrix::Part& p, int n_cus) { plan_part(p, n_cus); pack_part(p)
 // "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).
 int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
+    // HISPMV_PREP_TRACE=1: the phases of the host side of preprocessing on stderr (diagnostics)
+    static const bool trace = std::getenv("HISPMV_PREP_TRACE") != nullptr;
+    auto lap = [&, last = t0](const char* what) mutable {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[hispmv prep] %-28s %7.1f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
+        last = now;
+    };
+    if (trace) std::fprintf(stderr, "[hispmv prep] %-28s %7.1f ms (device: upload %.1f csr %.1f offsets %.1f stream %.1f download %.1f)\n", "COO -> CSR (-> stream)", t_csr * 1e3,
+                            c->last_prep_times.upload * 1e3, c->last_prep_times.csr_device * 1e3, c->last_prep_times.offsets_host * 1e3,
+                            c->last_prep_times.stream_device * 1e3, c->last_prep_times.download * 1e3);
     auto m = std::make_unique<Matrix>();
     m->rows = csr.rows; m->cols = csr.cols; m->nnz = csr.nnz();
     m->parts.emplace_back();
     m->parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
+    lap("slice stream (host) / adopt");
     plan_part(m->parts[0], c->n_cus);            // (its device layout: once the format is decided, below)
+    lap("launch plan");
     bool whole_packed = false;
     // Column tiling when the whole-matrix plan has to gather x through L2:
     //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
@@ -307,14 +321,19 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
 #pragma omp parallel for reduction(min : cmin) reduction(max : cmax) schedule(static)
     for (int64_t k = 0; k < nnz_all; ++k) { cmin = std::min(cmin, csr.col[(size_t)k]); cmax = std::max(cmax, csr.col[(size_t)k]); }
     if (cmax >= cmin) {
+        // (bins of 2^shift columns, at most 1024 of them; every 4th entry of a large matrix: the cut is a 0.1 % quantile.
+        // A 64-bit division per entry made this pass 44 ms on soc-Pokec's shape.)
         constexpr int kBins = 1024;
-        const int64_t bin_w = ((int64_t)cmax - cmin) / kBins + 1;
+        int shift = 0;
+        while ((((int64_t)cmax - cmin) >> shift) >= kBins) ++shift;
+        const int64_t bin_w = 1ll << shift;
+        const int64_t stride = nnz_all >= (4 << 20) ? 4 : 1;
         std::vector<int64_t> hist(kBins, 0);
 #pragma omp parallel
         {
             std::vector<int64_t> local(kBins, 0);
 #pragma omp for schedule(static) nowait
-            for (int64_t k = 0; k < nnz_all; ++k) local[(size_t)((csr.col[(size_t)k] - cmin) / bin_w)]++;
+            for (int64_t k = 0; k < nnz_all; k += stride) local[(size_t)((uint32_t)(csr.col[(size_t)k] - cmin) >> shift)] += stride;
 #pragma omp critical
             for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
         }
@@ -344,9 +363,11 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096;
     const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
     if (candidate && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
+        lap("column range / histogram");
         TtsGeometry g0;
         g0.zero_fill = c->tts_geometry == 4;        // HISPMV_TTS_GEOMETRY=zerofill: the standard sizes, no filler words (experiment)
         TtsStream ts = build_tts(csr, 0, g0);
+        lap("tile stream packer");
         if (ts.lines_per_gather <= 8.0 && std::getenv("HISPMV_TTS_SMALL")) {
             // experiment (off by default: measured slower): cheap gathers -> the half-LDS geometry, two workgroups per CU
             TtsGeometry small;
@@ -457,7 +478,9 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         }
     }
     csr = Csr{};
+    lap("column tiles (if any)");
     if (!whole_packed && tw == 0) pack_part(m->parts[0]);       // the whole-matrix stream stays: its device layout now
+    lap("device layout");
     for (auto& p : m->parts) {
         m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
         m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;

@@ -56,7 +56,7 @@ int ytile_floats_for(const SliceStream& st);
 // Device form of a planned stream (hispmv_format.h: structure-of-arrays slices, compact or wide per GROUP -- a group is
 // compact when it has a window and none of its elements lies outside it).
 struct DeviceStream {
-    std::vector<uint8_t> bytes;          // the slices, group after group
+    std::vector<uint8_t, DefaultInitAllocator<uint8_t>> bytes;   // the slices, group after group (uninitialised until the packing loop writes them)
     std::vector<int32_t> groups;         // n_groups x {frag_begin, frag_count, offset of the group's first slice in kSliceUnit, 1 = compact}
     int64_t compact_slices = 0;
 };

@@ -158,6 +158,15 @@ void sort_rows_by_column(Csr& m) {
     }
 }
 
+// First touch of a freshly allocated buffer by all threads (one write per page): a copy into it -- a device-to-host download,
+// done by one runtime thread -- then finds the pages mapped instead of faulting them in one by one.
+void prefault_parallel(void* p, size_t bytes) {
+    char* c = (char*)p;
+    const long long pages = (long long)((bytes + 4095) / 4096);
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < pages; ++i) c[(size_t)i * 4096] = 0;
+}
+
 // OpenMP threads of the host preprocessor: the CPUs this process may actually USE -- the cgroup quota (cpu.max) and the
 // affinity mask -- not the CPUs it can see.  The GPU boxes show 256 logical CPUs behind a 16-CPU quota: with 256 threads the
 // packer of soc-Pokec's shape spent 1.55 s where 16 threads take a third of that.  Left alone when OMP_NUM_THREADS is set.

@@ -43,11 +43,18 @@ struct Coo {
     std::vector<float> v;
 };
 
+// The big arrays (one entry per nonzero) use the default-initialising allocator: they are written exactly once, by a
+// device-to-host copy or a parallel loop -- value-initialising them first walked 490 MB of fresh pages on ONE core before
+// every download of soc-Pokec's shape.
+using IndexVec = std::vector<int32_t, DefaultInitAllocator<int32_t>>;
+using ValueVec = std::vector<float, DefaultInitAllocator<float>>;
+using WordVec = std::vector<uint64_t, DefaultInitAllocator<uint64_t>>;
+
 struct Csr {
     int32_t rows = 0, cols = 0;
     std::vector<int64_t> row_ptr;   // rows + 1
-    std::vector<int32_t> col;
-    std::vector<float> val;
+    IndexVec col;
+    ValueVec val;
     int64_t nnz() const { return row_ptr.empty() ? 0 : row_ptr.back(); }
 };
 
@@ -56,7 +63,7 @@ struct SliceStream {
     int64_t nnz = 0;          // real nonzeros
     int64_t n_elems = 0;      // nnz + one filler per empty row (before tail padding)
     int64_t n_slices = 0;
-    std::vector<uint64_t> words;        // n_slices * kSliceElems
+    WordVec words;                      // n_slices * kSliceElems
     std::vector<SliceHdr> hdr;          // n_slices
     std::vector<FixEntry> fix;          // rows split across slices, ascending row
     int64_t bytes() const { return (int64_t)words.size() * 8 + (int64_t)hdr.size() * 16 + (int64_t)fix.size() * 16; }
@@ -70,6 +77,8 @@ enum MtxFlavor {
 // Sets (once) the OpenMP thread count of the host preprocessor to the CPUs the process may use (cgroup cpu.max quota);
 // returns it.  Called by every entry point that preprocesses.
 int configure_host_threads();
+// Touches every page of [p, p + bytes) from all OpenMP threads (before a buffer is filled by a single-threaded copy).
+void prefault_parallel(void* p, size_t bytes);
 
 // MatrixMarket coordinate reader.  Throws std::runtime_error with the reference's
 // failure classes (not a MatrixMarket file / unsupported type) -- spmv-helper.cpp:50-71.

@@ -163,6 +163,7 @@ bool prep_on_device(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, c
     csr = Csr{};
     csr.rows = rows; csr.cols = cols;
     csr.row_ptr.resize((size_t)rows + 1); csr.col.resize(n); csr.val.resize(n);
+    prefault_parallel(csr.col.data(), (size_t)n * 4); prefault_parallel(csr.val.data(), (size_t)n * 4);
     PD_TRY(hipStreamSynchronize(stream));
     times.csr_device = secs_since(t0);
     t0 = std::chrono::steady_clock::now();
@@ -201,6 +202,7 @@ bool prep_on_device(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, c
     times.stream_device = secs_since(t0);
     t0 = std::chrono::steady_clock::now();
     st.words.resize((size_t)n_words);
+    prefault_parallel(st.words.data(), (size_t)n_words * 8);
     st.hdr.resize((size_t)st.n_slices);
     if (st.n_slices > 0) {
         PD_TRY(hipMemcpyAsync(st.words.data(), d_words.p, (size_t)n_words * 8, hipMemcpyDeviceToHost, stream));

@@ -83,15 +83,6 @@ struct TtsBlock {          // 32 B
     int32_t pad0, pad1, pad2;
 };
 
-// Allocator that leaves trivially constructible elements uninitialised: the 260 MB word array of soc-Pokec's shape is
-// written exactly once by the packer's parallel copies -- value-initialising it first walked every page on ONE core (1.8 of the
-// packer's 2.2 s in the build container, where a page fault is expensive), now the copying threads touch the pages.
-template <class T> struct DefaultInitAllocator : std::allocator<T> {
-    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
-    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
-    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
-};
-
 struct TtsStream {
     int32_t rows = 0, cols = 0;
     int64_t nnz = 0;
