@@ -362,7 +362,13 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     // a tile stream)
     const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096;
     const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
-    if (candidate && c->format_mode != 0 && (nnz_all >= tts_min || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
+    // (x of at most 256 KiB stays in L1 / L2 whatever the order of the gathers: the slice stream's per-element gathers are cheap
+    // there and a tile is a longer latency chain -- the 1024 x 8192 layer of apps/model_test.py: 10.0 us as a slice stream
+    // against 15.0 us as a tile stream, 8 vectors through `linear` 33 against 58 us.  Not 1 MiB: Si41Ge41H72 as an
+    // unstructured band, 742 KB of x, is 39.5 us as a tile stream and 45 as a slice stream; the pessimistic family's step
+    // 0.329 -> 0.363 ms with that threshold.)
+    const bool x_is_small = (int64_t)used * 4 <= (256 << 10);
+    if (candidate && c->format_mode != 0 && ((nnz_all >= tts_min && !x_is_small) || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
         lap("column range / histogram");
         TtsGeometry g0;
         g0.zero_fill = c->tts_geometry == 4;        // HISPMV_TTS_GEOMETRY=zerofill: the standard sizes, no filler words (experiment)

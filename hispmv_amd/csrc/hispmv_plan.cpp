@@ -143,7 +143,8 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         if (c.threads == 1024 && G != 0 && n / G < 512) continue;   // big workgroups only when there are plenty
         if (G == 0) {
             G = (n + (int64_t)n_cus * c.per_cu - 1) / ((int64_t)n_cus * c.per_cu);
-            if (G < (c.threads == 1024 ? 16 : 24)) continue;                                  // too little work to be worth a resident grid
+            static const int min_resident = std::getenv("HISPMV_PLAN_MIN_RESIDENT") ? std::atoi(std::getenv("HISPMV_PLAN_MIN_RESIDENT")) : 0;
+            if (G < (min_resident > 0 ? min_resident : c.threads == 1024 ? 16 : 24)) continue;   // too little work to be worth a resident grid
         } else {
             if (n / G < 1024 && G > 4) G /= 2;                      // small matrices: more, smaller workgroups
             if (n / G < 512 && G > 4) G /= 2;
