@@ -56,6 +56,7 @@ struct Matrix {
     std::vector<float> dense_host;
     int64_t n_slices = 0, n_elems = 0, n_split = 0, compact_slices = 0;
     int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
+    int tile_kind = 0;          // parts.size() > 1: 1 column ranges, 2 ranges of the offset from the (scaled) diagonal (band tiles)
     int format = 0;             // 0 slice stream, 1 transposed tile stream
     int index = -1;             // position in the context's handle list
     double tts_lines_per_gather = 0;
@@ -151,6 +152,7 @@ struct hispmv_ctx {
     int format_mode = 2;
     // geometry of a transposed tile stream: 0 the 8 K-row tiles always, 1 the tall geometry (two column parts of 16 K-row
     // tiles) for every tile stream, 2 auto (HISPMV_TTS_GEOMETRY=standard|tall|auto)
+    bool band_tiles = true;      // HISPMV_BAND_TILES=0: no diagonal-relative tiles for wide-band matrices
     int tts_geometry = 0;        // default: standard (measured: neither of the others is faster on soc-Pokec)
     int n_cus = 256;
 };
@@ -250,6 +252,39 @@ Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
     t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
+        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
+        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
+        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
+    }
+    return t;
+}
+
+// Offsets [o0, o1) from the (scaled) diagonal of a CSR matrix as its own CSR: row i keeps its columns in
+// [i*cols/rows + o0, i*cols/rows + o1) (global column ids are kept: x is shared).  open_lo / open_hi: no lower / upper bound.
+Csr band_tile(const Csr& m, int64_t o0, int64_t o1, bool open_lo, bool open_hi) {
+    Csr t;
+    t.rows = m.rows; t.cols = m.cols;
+    t.row_ptr.assign((size_t)m.rows + 1, 0);
+    auto bounds = [&](int32_t i, int32_t& c0, int32_t& c1) {
+        const int64_t cen = (int64_t)i * m.cols / m.rows;
+        c0 = open_lo ? 0 : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o0));
+        c1 = open_hi ? m.cols : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o1));
+    };
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        int32_t c0, c1; bounds(i, c0, c1);
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        t.row_ptr[(size_t)i + 1] = c1 > c0 ? std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0) : 0;
+    }
+    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
+    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        int32_t c0, c1; bounds(i, c0, c1);
         const int32_t* b = m.col.data() + m.row_ptr[i];
         const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
         const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
@@ -368,6 +403,72 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     // unstructured band, 742 KB of x, is 39.5 us as a tile stream and 45 as a slice stream; the pessimistic family's step
     // 0.329 -> 0.363 ms with that threshold.)
     const bool x_is_small = (int64_t)used * 4 <= (256 << 10);
+    // BAND TILES: a banded matrix whose band is wider than an LDS window -- every group of rows touches band + rows columns --
+    // is cut along the DIAGONAL: part t holds the elements whose offset from the (scaled) diagonal lies in the t-th of P equal
+    // ranges of the band.  A group of a part then touches (band / P + its rows) columns: a window that fits, every element in
+    // it, 6-byte elements from LDS instead of per-element gathers through the cache -- the reference's column tiling
+    // (tileAndPad spmv-helper.cpp:242-263) in the coordinates of a band.  Part 0 writes y, the others partial vectors that
+    // the tail launch merges; all parts share one grid.  (PFlow_742 as an unstructured band +-20000: 82 us as a tile stream.)
+    if (candidate && c->band_tiles && c->format_mode != 1 && nnz_all >= (4 << 20) && csr.rows > 1 && !x_is_small) {
+        constexpr int kBins = 4096;
+        const int64_t span = (int64_t)csr.cols + csr.rows;            // offsets lie in (-cols, cols)
+        int shift = 0;
+        while ((2 * span >> shift) >= kBins) ++shift;
+        std::vector<int64_t> hist(kBins, 0);
+#pragma omp parallel
+        {
+            std::vector<int64_t> local(kBins, 0);
+#pragma omp for schedule(static) nowait
+            for (int32_t i = 0; i < csr.rows; ++i) {
+                const int64_t cen = (int64_t)i * csr.cols / csr.rows;
+                for (int64_t k = csr.row_ptr[i]; k < csr.row_ptr[(size_t)i + 1]; ++k) local[(size_t)((csr.col[(size_t)k] - cen + span) >> shift)]++;
+            }
+#pragma omp critical
+            for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
+        }
+        const int64_t cut = nnz_all / 1000;
+        int lo = 0, hi = kBins - 1;
+        for (int64_t acc = 0; lo < hi && acc + hist[(size_t)lo] <= cut; ++lo) acc += hist[(size_t)lo];
+        for (int64_t acc = 0; hi > lo && acc + hist[(size_t)hi] <= cut; --hi) acc += hist[(size_t)hi];
+        const int64_t dmin = ((int64_t)lo << shift) - span, dmax = (((int64_t)hi + 1) << shift) - span - 1;
+        const int64_t W = dmax - dmin + 1;
+        constexpr int64_t kTarget = 20 * 1024;                        // offsets per part: leaves ~12 K floats of window for the rows of a group
+        lap("band histogram");
+        if (W > kTarget && W <= 8 * kTarget && W < (int64_t)used) {
+            const int P = (int)((W + kTarget - 1) / kTarget);
+            const int64_t width = (((W + P - 1) / P) + 63) & ~63LL;
+            std::vector<Matrix::Part> parts;
+            bool ok = true;
+            for (int t = 0; t < P && ok; ++t) {
+                Csr tile = band_tile(csr, dmin + t * width, dmin + (t + 1) * width, t == 0, t == P - 1);
+                parts.emplace_back();
+                parts.back().st = build_stream(tile);
+                finish_part(parts.back(), std::max(1, c->n_cus / P));
+                const Matrix::Part& q = parts.back();
+                ok = q.plan.lds_floats > 0 && q.plan.global_elems * 50 <= q.st.n_slices * (int64_t)kSliceElems;
+            }
+            lap("band tiles");
+            if (ok) {
+                m->parts = std::move(parts);
+                m->tile_kind = 2; m->col_tile_width = (int)width; m->col_tile_base = (int)dmin;
+                csr = Csr{};
+                for (auto& p : m->parts) {
+                    m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
+                    m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
+                    m->compact_slices += p.dstream.compact_slices;
+                }
+                m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of parts t > 0
+                m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
+                m->plan_lds = m->parts[0].plan.lds_floats;
+                m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
+                c->arena_used += m->device_bytes;
+                m->index = (int)c->mats.size();
+                c->mats.push_back(std::move(m));
+                return (int)c->mats.size() - 1;
+            }
+        }
+    }
     if (candidate && c->format_mode != 0 && ((nnz_all >= tts_min && !x_is_small) || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
         lap("column range / histogram");
         TtsGeometry g0;
@@ -453,7 +554,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         tbase = cmin & ~63;
     }
     if (tw > 0) {
-        m->col_tile_width = tw; m->col_tile_base = tbase;
+        m->col_tile_width = tw; m->col_tile_base = tbase; m->tile_kind = 1;
         m->parts.clear();
         for (int64_t c0 = tbase; c0 <= cmax; c0 += tw) {
             const bool first = c0 == tbase, last = c0 + tw > cmax;           // the end tiles are open-ended
@@ -472,7 +573,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             all_lds = all_lds && p.plan.lds_floats > 0 && p.plan.global_elems * 50 <= p.st.n_slices * (int64_t)kSliceElems;
         if ((lds_goal && !all_lds) || m->parts.size() < 2) {
             m->parts.clear();
-            m->col_tile_width = 0; m->col_tile_base = 0;
+            m->col_tile_width = 0; m->col_tile_base = 0; m->tile_kind = 0;
             m->parts.emplace_back();
             m->parts[0].st = build_stream(csr);
             finish_part(m->parts[0], c->n_cus);
@@ -680,6 +781,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(fork)");
     if (const char* env = std::getenv("HISPMV_FORMAT"))
         c->format_mode = !std::strcmp(env, "slices") ? 0 : !std::strcmp(env, "tts") ? 1 : 2;
+    if (const char* env_b = std::getenv("HISPMV_BAND_TILES")) c->band_tiles = std::atoi(env_b) != 0;
     if (const char* env_g = std::getenv("HISPMV_TTS_GEOMETRY")) c->tts_geometry = !std::strcmp(env_g, "standard") ? 0 : !std::strcmp(env_g, "tall") ? 1 : !std::strcmp(env_g, "paired") ? 3 : !std::strcmp(env_g, "zerofill") ? 4 : 2;
     if (const char* env = std::getenv("HISPMV_PREP"))
         c->prep_mode = !std::strcmp(env, "host") ? 0 : !std::strcmp(env, "device") ? 1 : 2;
@@ -1501,6 +1603,7 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->col_tiles = (int32_t)m.parts.size();
     out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width; out->col_tile_base = m.col_tile_base; out->compact_slices = (int32_t)std::min<int64_t>(m.compact_slices, INT32_MAX);
     out->format = m.format; out->tts_lines_per_gather = (float)m.tts_lines_per_gather;
+    out->tile_kind = m.parts.size() > 1 ? (m.tile_kind ? m.tile_kind : 1) : 0;
     return HISPMV_OK;
 }
 

@@ -165,6 +165,9 @@ typedef struct hispmv_matrix_info {
                                row tiles with LDS accumulators, elements streamed sorted by column, transposed through LDS; n_slices then
                                counts its 1024-word slices, n_split_rows the rows cut into pieces: longer than a tile and a quarter) */
     float tts_lines_per_gather;  /* format 1: distinct 128-byte lines of x per 64-lane gather (64 = no lane shares a line) */
+    int32_t tile_kind;      /* col_tiles > 1: 1 = tiles are column ranges (col_tile_base / col_tile_width above); 2 = BAND tiles: the same
+                               base / width describe ranges of the OFFSET col - row*cols/rows from the scaled diagonal (a banded matrix
+                               whose band is wider than an LDS window, cut along the diagonal); 0 = untiled */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);
