@@ -130,6 +130,32 @@ def host_cpu_info():
     return dict(logical=len(aff), physical=len(cores), cgroup_cpu_max=quota)
 
 
+def host_threads_per_rank(local_world: int) -> int:
+    """CPUs the job may use (physical cores in the affinity mask, capped by the cgroup quota) divided by the ranks on this host."""
+    info = host_cpu_info()
+    limit = info["logical"]
+    if info["cgroup_cpu_max"]:
+        limit = max(1, min(limit, int(info["cgroup_cpu_max"])))
+    return max(1, limit // max(1, local_world))
+
+
+def summarize_ranks(per_rank):
+    """rank_breakdown of the JSON line: per_rank = one dict per rank (rank, batch_us, exchange_us, nnz, rows, formats, ...);
+    adds min / max / mean over the ranks of every numeric field and the rank holding the maximum of the two times -- what one
+    needs to tell a slow rank (imbalanced shard, another format) from a slow exchange in the first N > 1 run."""
+    per_rank = sorted(per_rank, key=lambda q: q["rank"])
+    out = {"ranks": len(per_rank), "per_rank": per_rank}
+    for key in ("batch_us", "exchange_us", "step_us_eager", "nnz", "rows", "host_threads", "prep_upload_s"):
+        vals = [(q[key], q["rank"]) for q in per_rank if isinstance(q.get(key), (int, float))]
+        if not vals:
+            continue
+        xs = [v for v, _ in vals]
+        out[key] = {"min": min(xs), "max": max(xs), "mean": round(sum(xs) / len(xs), 3), "argmax_rank": max(vals)[1]}
+    if "batch_us" in out and out["batch_us"]["mean"] > 0:
+        out["batch_imbalance_max_over_mean"] = round(out["batch_us"]["max"] / out["batch_us"]["mean"], 4)
+    return out
+
+
 def cpu_baseline(workload: str, names, budget_s: float):
     """kind "port": mkl_sparse_s_mv / cblas_sgemv called as cpu/src/main.cpp:26-49,74-96 does (when the box has
     libmkl_rt) and the OpenMP restatement of cpu_spmv, each in a fresh child process that loads neither torch nor HIP,
@@ -362,9 +388,9 @@ class Runner:
         if seconds <= 0:
             return 0.0
         if self.dist_on:
-            # a step contains a collective: every rank must issue the SAME number of steps -- a fixed count instead of a
-            # wall-time bound (about 0.2-0.3 s of the 20-matrix step)
-            for _ in range(800):
+            # a step contains a collective: every rank must issue the SAME number of steps -- a count computed from `seconds`
+            # alone (800 steps per 0.3 s: about that long for the 20-matrix step), never from a rank's own clock
+            for _ in range(max(20, int(seconds / 0.3 * 800))):
                 step()
             self.fence()
             return (time.perf_counter() - t0) * 1e3
@@ -405,8 +431,25 @@ class Runner:
                 p = A @ x
                 A.data = np.abs(A.data)
                 a = A @ np.abs(x)
+            elif "path" in m:
+                # a real .mtx file: its host CSR comes from the library's host-only reader, flavour 1 = the cpu/ driver's loader
+                # (hispmv_prep_from_mtx; bit-exact against the reference's own helper_functions.cpp, tests/test_prep_host.py) --
+                # the same reader the handle was created with, so `matrices_without_host_csr` stays 0 when real files are present
+                try:
+                    from hispmv_amd.prep import prep_from_mtx
+                    pr = prep_from_mtx(m["path"], 1)
+                    A = sp.csr_matrix((pr.values.astype(np.float64), pr.col_idx, pr.row_ptr), shape=(pr.rows, pr.cols))
+                    del pr
+                    p = A @ x
+                    A.data = np.abs(A.data)
+                    a = A @ np.abs(x)
+                except Exception as ex:
+                    sys.stderr.write(f"bench.py: no host CSR for {m['name']} ({type(ex).__name__}: {str(ex)[:200]})\n")
+                    skipped += 1
+                    tails.append((0, 0, 0, 0.0, 0.0)); exp_heads.append(None)
+                    continue
             else:
-                skipped += 1                        # a real .mtx file loaded by the library: no host CSR to check against
+                skipped += 1
                 tails.append((0, 0, 0, 0.0, 0.0)); exp_heads.append(None)
                 continue
             y64 = ALPHA * p + BETA * b
@@ -486,6 +529,23 @@ def latest_traffic(n_launches):
     return None, None
 
 
+def recorded_one_gpu_strong(names):
+    """The n_gpus = 1 figure of the strong-scaling set from the committed bench line of the latest round
+    (profiles/r<N>_bench_line.json, chosen by the round tag), when it was measured on the same matrices."""
+    import re
+    def round_of(q):
+        m = re.match(r"r(\d+)_bench_line\.json$", q.name)
+        return int(m.group(1)) if m else -1
+    for c in sorted((q for q in (ROOT / "profiles").glob("r*_bench_line.json") if round_of(q) >= 0), key=round_of, reverse=True):
+        try:
+            ss = json.loads(c.read_text()).get("strong_scaling") or {}
+            if ss.get("n_gpus") == 1 and ss.get("matrices") == list(names) and ss.get("value"):
+                return float(ss["value"]), f"profiles/{c.name}"
+        except Exception:
+            continue
+    return None, None
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -496,6 +556,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+
+    # N ranks share one host: every rank's preprocessor gets its share of the CPUs this job may use (cgroup quota / affinity),
+    # not all of them (8 ranks x 16 threads on a 16-CPU quota oversubscribed the host 8-fold in round 3).  Set before the
+    # library is loaded: host_threads() reads HISPMV_HOST_THREADS once.
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > 1 and "HISPMV_HOST_THREADS" not in os.environ:
+        os.environ["HISPMV_HOST_THREADS"] = str(host_threads_per_rank(local_world))
 
     import torch
     import torch.distributed as dist
@@ -550,7 +617,7 @@ def main():
     exch = None
     if dist_on:
         from hispmv_amd.dist import BoundaryExchange
-        exch = BoundaryExchange(len(mats), R.dev)
+        exch = BoundaryExchange(len(mats), R.dev, fpga=fpga)
 
     # ---- the main timed region --------------------------------------------------------------------------------------
     n_streams = 1
@@ -600,7 +667,48 @@ def main():
     t_wall, t_dev = R.time_steps(step, args.steps, args.warmup)
     # self-check (outside the timed region): one more step, every rank's y against a host fp64 product of its shard
     y_err, y_rows, y_skipped = (R.verify(mats, step) if not args.no_verify else (None, 0, len(mats)))
-    y_checked = (y_err is not None) and y_err < 1e-5 and y_rows > 0
+    # True / False when rows were checked; None when nothing was checkable (--no-verify, or no host CSR for any matrix): skipped,
+    # not failed -- the line says so and the exit status stays 0
+    y_checked = None if (y_err is None or y_rows == 0) else bool(y_err < 1e-5)
+
+    # ---- rank breakdown (outside the timed region): the EAGER twin of the step with HIP events between its parts, on every rank
+    def rank_breakdown(mats_, exch_, reps=20):
+        batch = fpga.prepare_batch([m["idx"] for m in mats_], [m["x"].data_ptr() for m in mats_], [m["b"].data_ptr() for m in mats_],
+                                   [m["y"].data_ptr() for m in mats_])
+        if exch_ is not None:
+            exch_.prepare(mats_)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+        R.fence()
+        for k in range(reps + 3):
+            e = evs[max(0, k - 3)]
+            e[0].record(stream)
+            fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
+            e[1].record(stream)
+            if exch_ is not None:
+                exch_.run(mats_, ALPHA, prepared=True)
+            e[2].record(stream)
+        R.fence()
+        b_us = float(np.median([e[0].elapsed_time(e[1]) for e in evs])) * 1e3
+        x_us = float(np.median([e[1].elapsed_time(e[2]) for e in evs])) * 1e3 if exch_ is not None else None
+        fmts = {}
+        for m in mats_:
+            info = fpga.matrix_info(m["idx"])
+            key = ("dense" if info["is_dense"] else ("tile_stream" if info["format"] == 1 else "slices") + f'/{info["block_threads"]}t'
+                   + (f'/{info["col_tiles"]}{"band" if info["tile_kind"] == 2 else "col"}tiles' if info["col_tiles"] > 1 else ""))
+            fmts[key] = fmts.get(key, 0) + 1
+        mine = dict(rank=rank, batch_us=round(b_us, 2), exchange_us=None if x_us is None else round(x_us, 2),
+                    step_us_eager=round(b_us + (x_us or 0.0), 2), nnz=int(sum(m["nnz"] for m in mats_)), rows=int(sum(m["rows"] for m in mats_)),
+                    cut_heads=int(sum(1 for m in mats_ if m.get("shard") is not None and m["shard"].head_open)),
+                    cut_tails=int(sum(1 for m in mats_ if m.get("shard") is not None and m["shard"].tail_open)),
+                    formats=fmts, host_threads=int(os.environ.get("HISPMV_HOST_THREADS", "0")) or None, prep_upload_s=round(t_prep, 2))
+        if dist_on:
+            allr = [None] * dist.get_world_size()
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        return summarize_ranks(allr)
+
+    breakdown = rank_breakdown(mats, exch) if args.launch == "batch" else None
 
     def alg_bytes(m):
         if m.get("dense") is not None:
@@ -675,14 +783,19 @@ def main():
             sexch = None
             if world > 1:
                 from hispmv_amd.dist import BoundaryExchange
-                sexch = BoundaryExchange(len(smats), R.dev)
+                sexch = BoundaryExchange(len(smats), R.dev, fpga=fpga)
             sstep = R.batch_step(smats, sexch)
             R.preheat(sstep, min(args.preheat, 0.15))
             tw, td = R.time_steps(sstep, args.steps, args.warmup)
             s_err, s_rows, _ = (R.verify(smats, sstep) if not args.no_verify else (None, 0, 0))
             fl = sum(M.flops(m.get("full_rows", m["rows"]), m.get("full_nnz", m["nnz"])) for m in smats)
             by = sum(M.algorithmic_bytes(m.get("full_rows", m["rows"]), m["cols"], m.get("full_nnz", m["nnz"])) for m in smats)
-            extras["strong_scaling"] = {"matrices": [m["name"] for m in smats], "n_gpus": world, "value": round(fl * args.steps / tw / 1e9, 2),
+            ss_val = fl * args.steps / tw / 1e9
+            rec1, rec1_src = recorded_one_gpu_strong([m["name"] for m in smats])
+            extras["strong_scaling"] = {"matrices": [m["name"] for m in smats], "n_gpus": world, "value": round(ss_val, 2),
+                                        "rank_breakdown": rank_breakdown(smats, sexch) if world > 1 else None,
+                                        "efficiency": {"value": None if not rec1 else round(ss_val / (world * rec1), 4), "one_gpu_value": rec1, "one_gpu_source": rec1_src,
+                                                       "definition": "value / (n_gpus x the recorded n_gpus = 1 value of the same matrices)"},
                                         "unit": "GFLOP/s", "ms_per_step": round(tw / args.steps * 1e3, 4),
                                         "hbm_gbs_algorithmic": round(by * args.steps / tw / 1e9, 1), "scaling": "strong",
                                         "y_checked": bool(s_err is not None and s_err < 1e-5 and s_rows > 0), "y_max_backward_error": s_err,
@@ -730,7 +843,8 @@ def main():
                      "model": "BASELINE.json configs[3]: apps/model_test.py layers 4096->8192 dense, 8192->8192 d=0.1, 8192->1024 d=0.25, one launch per layer"}
         # every kernel with >= 10 % of a step's kernel time (profiles/r3_kernel_stats_single_stream.csv)
         dominant = {"set": "spmv_slices_multi_kernel (two grids per step: the 1024-thread and the 256-thread slice streams) + "
-                           "spmv_tts_multi_kernel (the tile streams: soc-Pokec, nxp1, analytics, boyd2, language); + one fix-up and one merge launch per step"
+                           "spmv_tts_multi_kernel (the tile streams: soc-Pokec, nxp1, analytics, boyd2, language); + ONE tail launch per step "
+                           "(spmv_tail_multi_kernel: cut rows of every part + merge of the column-tile partial vectors)"
                            if args.launch == "batch" else "spmv_slices_kernel / spmv_tts_kernel (+ carry fix-up launches)",
                     "powerlaw": "spmv_tts_multi_kernel (both matrices are tile streams; + one fix-up launch for the rows cut into pieces)",
                     "dense": "gemv_rows_multi_kernel",
@@ -769,11 +883,12 @@ def main():
                          "avg_launch_us": round(t_dev / launches * 1e6, 3),
                          "note": "achieved = sum over the workload of the algorithmic bytes (SpMV: 8*nnz+16*rows+4, GeMV: 4*rows*cols+4*cols+8*rows) "
                                  "/ HIP-event time of the timed region on the launch stream"},
-            "y_checked": bool(y_checked),
+            "y_checked": y_checked,
             "y_check": {"max_backward_error": y_err, "rows_checked": y_rows, "matrices_without_host_csr": y_skipped, "gate": 1e-5,
                         "how": "one step after the timed region; every rank: host fp64 product (scipy CSR) of its shard, cut rows with the "
                                "gathered fp64 tails of the ranks before it"},
             "preheat_ms": round(preheat_ms, 1),
+            "rank_breakdown": breakdown,
             "launch_classes": classes,
             "host": {"gen_s": round(t_gen, 1), "prep_upload_s": round(t_prep, 1)},
         }
@@ -789,7 +904,7 @@ def main():
     fpga.close()
     if dist_on:
         dist.destroy_process_group()
-    if not args.no_verify and not y_checked:
+    if not args.no_verify and y_checked is False:
         sys.exit(f"bench.py: the y self-check failed (max backward error {y_err}, rows checked {y_rows})")
 
 

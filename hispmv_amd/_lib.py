@@ -50,8 +50,8 @@ SIGNATURES = {
     "hispmv_version": (C.c_char_p, []),
     "hispmv_host_threads": (C.c_int, []),
     "hispmv_free_failures": (C.c_int64, []),
-    "hispmv_boundary_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "hispmv_boundary_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "hispmv_boundary_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hispmv_boundary_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hispmv_create": (C.c_int, [C.POINTER(_p), C.c_char_p] + [C.c_int] * 9),
     "hispmv_destroy": (None, [_p]),
     "hispmv_last_error": (C.c_char_p, [_p]),

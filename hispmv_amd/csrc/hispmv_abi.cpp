@@ -130,10 +130,20 @@ struct hispmv_ctx {
         std::vector<BatchLaunch> launches;
         int64_t stream_bytes = 0;     // 8 B per entry of the call's sparse matrices: decides whether side streams pay
         int lanes = 1;                // streams the main launches are spread over
-        // HISPMV_BATCH_GRAPH=1 (experiment): the launches of a two-stream call captured once into a HIP graph and replayed
-        hipGraphExec_t graph = nullptr;
-        hipGraph_t graph_src = nullptr;      // the captured graph `graph` was instantiated from (kept: its node handles patch alpha)
-        float graph_alpha = 0.0f;
+        // The launches of a two-stream call captured once into a HIP graph and replayed.  TWO executables of the same captured
+        // graph, each with the alpha it was last patched to and an event recorded behind its last launch: a call with another
+        // alpha patches the executable that is NOT in flight (hipGraphExecKernelNodeSetParams rewrites the executable's kernel
+        // arguments in place -- patching one whose earlier launch is still queued could run that launch with the new alpha),
+        // and waits for that executable's own last launch -- two calls back -- before it touches it.
+        struct GraphSlot {
+            hipGraphExec_t exec = nullptr;
+            float alpha = 0.0f;
+            hipEvent_t done = nullptr;       // recorded on the launch stream behind the last launch of `exec`
+            bool launched = false;
+            uint64_t last_use = 0;
+        } slot[2];
+        uint64_t use_counter = 0;
+        hipGraph_t graph_src = nullptr;      // the captured graph the executables were instantiated from (kept: its node handles patch alpha)
         int runs = 0;
     };
     std::vector<BatchPlan> batch_plans;
@@ -196,7 +206,12 @@ template <class T> void host_free(T*& p) {
 
 void free_batch_plans(hispmv_ctx* c) {
     for (auto& p : c->batch_plans) {
-        if (p.graph) { (void)hipGraphExecDestroy(p.graph); p.graph = nullptr; }
+        for (auto& g : p.slot) {
+            if (g.launched && g.done) (void)hipEventSynchronize(g.done);
+            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            if (g.done) { (void)hipEventDestroy(g.done); g.done = nullptr; }
+            g.launched = false;
+        }
         if (p.graph_src) { (void)hipGraphDestroy(p.graph_src); p.graph_src = nullptr; }
         for (auto& l : p.launches) { dev_free(l.d_table); dev_free(l.d_table2); }
     }
@@ -242,7 +257,7 @@ Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
     Csr t;
     t.rows = m.rows; t.cols = m.cols;
     t.row_ptr.assign((size_t)m.rows + 1, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
         const int32_t* b = m.col.data() + m.row_ptr[i];
         const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
@@ -250,7 +265,7 @@ Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
     }
     for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
     t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
         const int32_t* b = m.col.data() + m.row_ptr[i];
         const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
@@ -273,7 +288,7 @@ Csr band_tile(const Csr& m, int64_t o0, int64_t o1, bool open_lo, bool open_hi) 
         c0 = open_lo ? 0 : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o0));
         c1 = open_hi ? m.cols : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o1));
     };
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
         int32_t c0, c1; bounds(i, c0, c1);
         const int32_t* b = m.col.data() + m.row_ptr[i];
@@ -282,7 +297,7 @@ Csr band_tile(const Csr& m, int64_t o0, int64_t o1, bool open_lo, bool open_hi) 
     }
     for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
     t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
         int32_t c0, c1; bounds(i, c0, c1);
         const int32_t* b = m.col.data() + m.row_ptr[i];
@@ -353,7 +368,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
     // (a shard also holds a few rows of the next block) -- they go to the first / last tile, which are open-ended
     int32_t cmin = INT32_MAX, cmax = -1;
     const int64_t nnz_all = csr.nnz();
-#pragma omp parallel for reduction(min : cmin) reduction(max : cmax) schedule(static)
+#pragma omp parallel for num_threads(host_threads()) reduction(min : cmin) reduction(max : cmax) schedule(static)
     for (int64_t k = 0; k < nnz_all; ++k) { cmin = std::min(cmin, csr.col[(size_t)k]); cmax = std::max(cmax, csr.col[(size_t)k]); }
     if (cmax >= cmin) {
         // (bins of 2^shift columns, at most 1024 of them; every 4th entry of a large matrix: the cut is a 0.1 % quantile.
@@ -364,7 +379,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         const int64_t bin_w = 1ll << shift;
         const int64_t stride = nnz_all >= (4 << 20) ? 4 : 1;
         std::vector<int64_t> hist(kBins, 0);
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
         {
             std::vector<int64_t> local(kBins, 0);
 #pragma omp for schedule(static) nowait
@@ -415,7 +430,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
         int shift = 0;
         while ((2 * span >> shift) >= kBins) ++shift;
         std::vector<int64_t> hist(kBins, 0);
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
         {
             std::vector<int64_t> local(kBins, 0);
 #pragma omp for schedule(static) nowait
@@ -712,15 +727,28 @@ int launch_matrix_vectors(hispmv_ctx* c, Matrix& m, int64_t vecs, const float* d
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-HISPMV_API int hispmv_boundary_pack(const float* const* d_last, const float* d_mask, float* d_send, int32_t n, void* stream) {
-    if (n < 0 || (n > 0 && (!d_last || !d_mask || !d_send))) return HISPMV_EINVAL;
-    return launch_boundary_pack(d_last, d_mask, d_send, n, (hipStream_t)stream) == hipSuccess ? HISPMV_OK : HISPMV_EDEVICE;
+// `stream` NULL = the context's stream, exactly as in hispmv_spmv_device / hispmv_spmv_device_batch: a caller that passes NULL
+// everywhere gets its SpMVs and its boundary kernels on ONE queue, in order.  (Until round 3 NULL meant HIP's null stream here:
+// the boundary kernels then did not wait for SpMVs issued with NULL on the context's non-blocking stream.)
+HISPMV_API int hispmv_boundary_pack(hispmv_ctx* c, const float* const* d_last, const float* d_mask, float* d_send, int32_t n, void* stream) {
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n < 0 || (n > 0 && (!d_last || !d_mask || !d_send))) return fail(c, HISPMV_EINVAL, "bad boundary_pack arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (stream) c->user_stream = (hipStream_t)stream;
+    const hipError_t e = launch_boundary_pack(d_last, d_mask, d_send, n, stream ? (hipStream_t)stream : c->stream);
+    return e == hipSuccess ? HISPMV_OK : hip_fail(c, e, "launch_boundary_pack");
 }
 
-HISPMV_API int hispmv_boundary_apply(float* const* d_first, const float* d_recv, const float* d_weights, int32_t n,
+HISPMV_API int hispmv_boundary_apply(hispmv_ctx* c, float* const* d_first, const float* d_recv, const float* d_weights, int32_t n,
                                      int32_t world, void* stream) {
-    if (n < 0 || world < 1 || (n > 0 && (!d_first || !d_recv || !d_weights))) return HISPMV_EINVAL;
-    return launch_boundary_apply(d_first, d_recv, d_weights, n, world, (hipStream_t)stream) == hipSuccess ? HISPMV_OK : HISPMV_EDEVICE;
+    if (!c) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n < 0 || world < 1 || (n > 0 && (!d_first || !d_recv || !d_weights))) return fail(c, HISPMV_EINVAL, "bad boundary_apply arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (stream) c->user_stream = (hipStream_t)stream;
+    const hipError_t e = launch_boundary_apply(d_first, d_recv, d_weights, n, world, stream ? (hipStream_t)stream : c->stream);
+    return e == hipSuccess ? HISPMV_OK : hip_fail(c, e, "launch_boundary_apply");
 }
 
 HISPMV_API const char* hispmv_version(void) { return "hispmv-amd 0.2.0 gfx950"; }
@@ -735,7 +763,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
                              int urams, int fp_acc_latency, int dense, int pre_acc, int row_dist) {
     if (!out) return fail(nullptr, HISPMV_EINVAL, "out is NULL");
     *out = nullptr;
-    configure_host_threads();       // OpenMP threads of the preprocessor = the CPUs this process may use (cgroup quota)
+    host_threads();       // OpenMP threads of the preprocessor = the CPUs this process may use (cgroup quota)
     // same argument checks as fpga_handle.cpp:51-52,70-71
     if (device_id < 0) return fail(nullptr, HISPMV_EINVAL, "Device ID must be a non-negative integer.");
     if (!xclbin_path || !*xclbin_path) return fail(nullptr, HISPMV_EINVAL, "XCLBIN path is empty.");
@@ -1511,19 +1539,46 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     const bool caller_captures = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
     (void)hipGetLastError();
     if (c->batch_graphs && lanes > 1 && !caller_captures) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
-        auto drop_graph = [&]() {
-            if (plan->graph) { (void)hipGraphExecDestroy(plan->graph); plan->graph = nullptr; }
+        using Slot = hispmv_ctx::BatchPlan::GraphSlot;
+        auto drop_graphs = [&]() {
+            for (Slot& g : plan->slot) {
+                if (g.launched && g.done) (void)hipEventSynchronize(g.done);
+                if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+                g.launched = false;
+            }
             if (plan->graph_src) { (void)hipGraphDestroy(plan->graph_src); plan->graph_src = nullptr; }
         };
-        if (plan->graph && plan->graph_alpha != alpha) {
-            // another alpha on the same call: patch the kernel nodes of the instantiated graph (no capture, no instantiation)
-            if (plan->graph_src && graph_set_alpha(plan->graph, plan->graph_src, alpha) == hipSuccess) { plan->graph_alpha = alpha; c->graph_alpha_updates++; }
-            else { (void)hipGetLastError(); drop_graph(); }
-        }
-        if (plan->graph) {
-            if (hipGraphLaunch(plan->graph, s) == hipSuccess) return HISPMV_OK;
-            (void)hipGetLastError();
-            drop_graph();
+        auto launch_slot = [&](Slot& g) -> bool {
+            if (hipGraphLaunch(g.exec, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (!g.done && hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g.done = nullptr; }
+            // (without the event the executable can never be patched safely: its alpha stays what it is, see below)
+            g.launched = g.done && hipEventRecord(g.done, s) == hipSuccess;
+            if (!g.launched) (void)hipGetLastError();
+            g.last_use = ++plan->use_counter;
+            return true;
+        };
+        if (plan->graph_src) {
+            // 1. an executable that already carries this alpha
+            Slot* pick = nullptr;
+            for (Slot& g : plan->slot) if (g.exec && g.alpha == alpha) { pick = &g; break; }
+            if (!pick) {
+                // 2. another alpha on the same call: no capture -- a second executable of the captured graph the first time,
+                //    afterwards the executable used longest ago, patched once ITS last launch has completed
+                Slot* victim = nullptr;
+                for (Slot& g : plan->slot) if (!g.exec) { victim = &g; break; }
+                if (victim) {
+                    if (hipGraphInstantiate(&victim->exec, plan->graph_src, nullptr, nullptr, 0) == hipSuccess) { c->graph_instantiations++; victim->launched = false; }
+                    else { (void)hipGetLastError(); victim->exec = nullptr; victim = nullptr; }
+                }
+                if (!victim) victim = plan->slot[0].last_use <= plan->slot[1].last_use ? &plan->slot[0] : &plan->slot[1];
+                bool ok = victim->exec != nullptr;
+                if (ok && victim->launched) ok = victim->done && hipEventSynchronize(victim->done) == hipSuccess;
+                if (ok) ok = graph_set_alpha(victim->exec, plan->graph_src, alpha) == hipSuccess;
+                if (ok) { victim->alpha = alpha; c->graph_alpha_updates++; pick = victim; }
+                else (void)hipGetLastError();
+            }
+            if (pick && launch_slot(*pick)) return HISPMV_OK;
+            drop_graphs();
         }
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (plan->runs >= 1 && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone &&
@@ -1532,15 +1587,15 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
             hipGraph_t g = nullptr;
             const hipError_t e_end = hipStreamEndCapture(s, &g);
             if (rc != HISPMV_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-            drop_graph();
+            drop_graphs();
             hipError_t e = e_end;
-            if (e == hipSuccess) e = hipGraphInstantiate(&plan->graph, g, nullptr, nullptr, 0);
+            Slot& g0 = plan->slot[0];
+            if (e == hipSuccess) e = hipGraphInstantiate(&g0.exec, g, nullptr, nullptr, 0);
             if (e == hipSuccess) c->graph_instantiations++;
             plan->graph_src = g;
-            if (e == hipSuccess) e = hipGraphLaunch(plan->graph, s);
-            if (e == hipSuccess) { plan->graph_alpha = alpha; return HISPMV_OK; }
+            if (e == hipSuccess) { g0.alpha = alpha; g0.launched = false; if (launch_slot(g0)) return HISPMV_OK; }
             (void)hipGetLastError();
-            drop_graph();
+            drop_graphs();
             c->batch_graphs = false;               // this runtime / stream does not take it: plain launches from here on
         } else {
             (void)hipGetLastError();
@@ -1610,12 +1665,12 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
 // ---- host-only preprocessor access ---------------------------------------------------------------
 HISPMV_API const char* hispmv_prep_last_error(void) { return g_prep_err.c_str(); }
 
-HISPMV_API int hispmv_host_threads(void) { return configure_host_threads(); }
+HISPMV_API int hispmv_host_threads(void) { return host_threads(); }
 
 HISPMV_API int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* r, const int32_t* cl, const float* v,
                                     int64_t nnz, int32_t rows, int32_t cols) {
     if (!out) return HISPMV_EINVAL;
-    configure_host_threads();
+    host_threads();
     *out = nullptr;
     if (rows <= 0 || cols <= 0 || nnz < 0) { g_prep_err = "bad sparse matrix arguments"; return HISPMV_EINVAL; }
     try {
@@ -1648,7 +1703,7 @@ HISPMV_API int hispmv_prep_from_coo_device(hispmv_prep** out, int device_id, con
 }
 
 HISPMV_API int hispmv_prep_from_mtx(hispmv_prep** out, const char* path, int flavor) {
-    configure_host_threads();
+    host_threads();
     if (!out) return HISPMV_EINVAL;
     *out = nullptr;
     if (!path || (flavor != 0 && flavor != 1)) { g_prep_err = "bad arguments"; return HISPMV_EINVAL; }

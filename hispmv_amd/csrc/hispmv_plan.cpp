@@ -152,7 +152,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         const int64_t ng = (n + G - 1) / G;
         const int64_t limit = c.cap / kFragBlock;
         int64_t staged_blocks = 0, global_elems = 0, runs = 0, two_way_elems = 0;
-#pragma omp parallel reduction(+ : staged_blocks, global_elems, runs, two_way_elems)
+#pragma omp parallel num_threads(host_threads()) reduction(+ : staged_blocks, global_elems, runs, two_way_elems)
         {
             BlockSet bs;
 #pragma omp for schedule(dynamic, 16)
@@ -199,7 +199,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
     best.groups.assign((size_t)ng, GroupDesc{0, 0, 0, 0});
     best.slice_spills.assign((size_t)n, 0);
     std::vector<std::vector<Frag>> gfrags((size_t)ng);
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
     {
         BlockSet bs;
         std::vector<int32_t> rank_of;    // dense path: block - b_lo -> rank
@@ -270,7 +270,7 @@ DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan) {
     }
     if (off[(size_t)ng] / kSliceUnit > INT32_MAX) throw std::length_error("stream larger than 4 TiB");
     d.bytes.resize((size_t)off[(size_t)ng]);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 4)
     for (int64_t g = 0; g < ng; ++g) {
         const int64_t s0 = g * G, s1 = std::min(n, s0 + G);
         for (int64_t sl = s0; sl < s1; ++sl) {

@@ -10,6 +10,9 @@
 #include <stdexcept>
 #ifdef _OPENMP
 #include <omp.h>
+#include <sched.h>
+
+#include <mutex>
 #endif
 
 namespace hispmv {
@@ -116,7 +119,7 @@ Coo read_mtx(const std::string& path, MtxFlavor flavor) {
         chunks.push_back(Chunk{b, e, {}, {}, {}});
         b = e;
     }
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 1)
     for (long i = 0; i < (long)chunks.size(); ++i) parse(chunks[(size_t)i], nz);
     long taken = 0;
     for (Chunk& k : chunks) {
@@ -139,7 +142,7 @@ Coo read_mtx(const std::string& path, MtxFlavor flavor) {
 // of a slice, column tiles) takes a row's first / last column from its ends.
 void sort_rows_by_column(Csr& m) {
     const int32_t rows = m.rows;
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
     {
         std::vector<std::pair<int32_t, float>> tmp;
 #pragma omp for schedule(dynamic, 256)
@@ -163,31 +166,45 @@ void sort_rows_by_column(Csr& m) {
 void prefault_parallel(void* p, size_t bytes) {
     char* c = (char*)p;
     const long long pages = (long long)((bytes + 4095) / 4096);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (long long i = 0; i < pages; ++i) c[(size_t)i * 4096] = 0;
 }
 
-// OpenMP threads of the host preprocessor: the CPUs this process may actually USE -- the cgroup quota (cpu.max) and the
-// affinity mask -- not the CPUs it can see.  The GPU boxes show 256 logical CPUs behind a 16-CPU quota: with 256 threads the
-// packer of soc-Pokec's shape spent 1.55 s where 16 threads take a third of that.  Left alone when OMP_NUM_THREADS is set.
-int configure_host_threads() {
-    static int chosen = 0;
-    if (chosen) return chosen;
-    int n = omp_get_num_procs();
-    if (!std::getenv("OMP_NUM_THREADS")) {
-        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[64] = {0}; long long per = 0;
-            if (std::fscanf(f, "%63s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) {
-                const long long quota = (std::atoll(q) + per - 1) / per;
-                if (quota >= 1 && quota < n) n = (int)quota;
-            }
-            std::fclose(f);
+// OpenMP threads of the host preprocessor: the CPUs this process may actually USE -- the cgroup quota (v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us) and the affinity mask -- not the CPUs it can see.  The GPU boxes show 256 logical CPUs
+// behind a 16-CPU quota: with 256 threads the packer of soc-Pokec's shape spent 1.55 s where 16 threads take a third of that.
+// HISPMV_HOST_THREADS overrides (bench.py --gpus N gives every rank its share: quota / LOCAL_WORLD_SIZE), else OMP_NUM_THREADS
+// is honoured.  The count stays PRIVATE to the library: every parallel region carries num_threads(host_threads()); the
+// process-global OpenMP setting of the embedding application (torch CPU ops, an MKL baseline sharing the runtime) is never
+// touched (until round 3 the first hispmv_create called omp_set_num_threads).
+int host_threads() {
+    static std::once_flag once;
+    static int chosen = 1;
+    std::call_once(once, [] {
+        auto env_int = [](const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; };
+        int n = env_int("HISPMV_HOST_THREADS");
+        if (n <= 0) n = env_int("OMP_NUM_THREADS");
+        if (n <= 0) {
+            n = omp_get_num_procs();
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1 && a < n) n = a; }
+            auto quota_of = [](const char* path_quota, const char* path_period) -> long long {
+                long long q = -1, per = 0;
+                if (FILE* f = std::fopen(path_quota, "r")) {
+                    char tok[64] = {0};
+                    if (path_period) { if (std::fscanf(f, "%63s", tok) == 1) q = std::atoll(tok); }
+                    else if (std::fscanf(f, "%63s %lld", tok, &per) == 2 && std::strcmp(tok, "max") != 0) q = std::atoll(tok);
+                    std::fclose(f);
+                }
+                if (path_period) { if (FILE* f = std::fopen(path_period, "r")) { if (std::fscanf(f, "%lld", &per) != 1) per = 0; std::fclose(f); } }
+                return (q > 0 && per > 0) ? (q + per - 1) / per : -1;
+            };
+            long long quota = quota_of("/sys/fs/cgroup/cpu.max", nullptr);
+            if (quota < 0) quota = quota_of("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+            if (quota >= 1 && quota < n) n = (int)quota;
         }
-        omp_set_num_threads(std::max(1, n));
-    } else {
-        n = omp_get_max_threads();
-    }
-    chosen = std::max(1, n);
+        chosen = std::max(1, n);
+    });
     return chosen;
 }
 
@@ -202,7 +219,7 @@ Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const 
     m.val.resize((size_t)nnz);
 
     bool bad = false;
-#pragma omp parallel for schedule(static) reduction(|| : bad)
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(|| : bad)
     for (int64_t i = 0; i < nnz; ++i)
         bad = bad || (r[i] < 0 || r[i] >= rows || c[i] < 0 || c[i] >= cols);
     if (bad) throw std::out_of_range("COO index outside matrix dimensions");
@@ -213,7 +230,7 @@ Csr coo_to_csr(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, const 
     // (spmv-helper.cpp:139-227), ~87 % of its preprocessing time.
     int nt = 1;
 #ifdef _OPENMP
-    nt = std::max(1, omp_get_max_threads());
+    nt = host_threads();
 #endif
     nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, nnz / (1 << 20)));
     if (nt <= 1) {
@@ -304,7 +321,7 @@ SliceStream build_stream(const Csr& m) {
     st.words.assign((size_t)(st.n_slices * S), pack_elem(0.0f, 0, false));
     st.hdr.assign((size_t)st.n_slices, SliceHdr{0, 0, 0, 1});
 
-#pragma omp parallel for schedule(dynamic, 1024)
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 1024)
     for (int32_t i = 0; i < R; ++i) {
         const int64_t s = m.row_ptr[i], e = m.row_ptr[(size_t)i + 1];
         const int64_t span = eoff[(size_t)i + 1] - eoff[i];          // real elements (or one filler), then the extension
@@ -315,7 +332,7 @@ SliceStream build_stream(const Csr& m) {
     }
 
     std::vector<uint8_t> has_fix((size_t)st.n_slices, 0);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 64)
     for (int64_t sl = 0; sl < st.n_slices; ++sl) {
         const int64_t b = sl * S, e = std::min(b + S, st.n_elems);
         // rows that END before element b

@@ -74,9 +74,10 @@ enum MtxFlavor {
     kFlavorCpu = 1       // cpu/ driver semantics (helper_functions.cpp:91-146)
 };
 
-// Sets (once) the OpenMP thread count of the host preprocessor to the CPUs the process may use (cgroup cpu.max quota);
-// returns it.  Called by every entry point that preprocesses.
-int configure_host_threads();
+// OpenMP threads of the host preprocessor = the CPUs the process may use (cgroup quota, affinity mask; HISPMV_HOST_THREADS /
+// OMP_NUM_THREADS override), decided once.  Every parallel region of the library carries num_threads(host_threads()); the
+// process-global OpenMP setting is never changed.
+int host_threads();
 // Touches every page of [p, p + bytes) from all OpenMP threads (before a buffer is filled by a single-threaded copy).
 void prefault_parallel(void* p, size_t bytes);
 

@@ -163,7 +163,7 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     std::vector<TileOut> outs(nt);
     int col_bits = 1;
     while (col_bits < 31 && (1ll << col_bits) < (long long)m.cols) ++col_bits;
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
     {
         std::vector<Elem> el, tmp;
         std::vector<int32_t> cnt((size_t)geo.max_rows), start((size_t)geo.max_rows), seen((size_t)geo.max_rows);
@@ -267,7 +267,7 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     S.words.resize((size_t)n_slices * kTtsChunk * 8);
     S.col_base.resize(cb_off[nt]); S.flags.resize(fl_off[nt]); S.chunk_info.resize(ci_off[nt]);
     double lines = 0; int64_t gathers = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : lines, gathers)
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 1) reduction(+ : lines, gathers)
     for (long long tt = 0; tt < (long long)nt; ++tt) {
         const size_t t = (size_t)tt;
         TileOut& o = outs[t];
@@ -303,7 +303,7 @@ Csr csr_column_range(const Csr& m, int32_t c0, int32_t c1) {
     Csr t;
     t.rows = m.rows; t.cols = m.cols;
     t.row_ptr.assign((size_t)m.rows + 1, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
         const int32_t* b = m.col.data() + m.row_ptr[i];
         const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
@@ -311,7 +311,7 @@ Csr csr_column_range(const Csr& m, int32_t c0, int32_t c1) {
     }
     for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
     t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t i = 0; i < m.rows; ++i) {
         const int32_t* b = m.col.data() + m.row_ptr[i];
         const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];

@@ -140,11 +140,16 @@ class BoundaryExchange:
     are row-aligned blocks (nothing is cut) and contribute zeros -- the collective still runs, it is the
     path's exchange step.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the
     CPU tests).  With `world`/`rank` given explicitly the object touches no process group: it is one of the
-    virtual ranks of a LoopbackWorld (several ranks in one process, the all_gather a concatenation)."""
+    virtual ranks of a LoopbackWorld (several ranks in one process, the all_gather a concatenation).
+    `fpga` is the FpgaHandle whose SpMVs produce the y vectors: on the GPU the two boundary kernels are launches of ITS context
+    (include/hispmv.h: one meaning of a NULL stream for SpMVs and boundary kernels alike); `stream` is the raw stream handle
+    both go to -- None = the current torch stream at prepare/run time, 0 = the context's own stream."""
 
-    def __init__(self, n_mats: int, device, world: int | None = None, rank: int | None = None):
+    def __init__(self, n_mats: int, device, world: int | None = None, rank: int | None = None, fpga=None, stream: int | None = None):
         import torch
         self.torch = torch
+        self.fpga = fpga
+        self.stream_arg = stream
         self.loopback = world is not None
         if self.loopback:
             self.dist = None
@@ -218,20 +223,22 @@ class BoundaryExchange:
             self._setup(mats)
         if self.send.is_cuda:
             self._device_tables(mats)
-            self._stream = self.torch.cuda.current_stream(self.device).cuda_stream
+            self._stream = self._pick_stream()
+
+    def _pick_stream(self) -> int:
+        if self.fpga is None:
+            raise RuntimeError("BoundaryExchange on a GPU needs the FpgaHandle whose context launches the boundary kernels (fpga=...)")
+        return int(self.stream_arg) if self.stream_arg is not None else self.torch.cuda.current_stream(self.device).cuda_stream
 
     def pack(self, mats, prepared: bool = False) -> None:
         """First half of a step: the tails (y_local[-1] of rows this rank does not own: alpha*partial, its bias entry
         was zeroed) -> self.send.  On the GPU one tiny launch of libhispmv."""
         torch = self.torch
         if self.send.is_cuda:
-            from ._lib import lib
             if not prepared:
                 self._device_tables(mats)
-                self._stream = torch.cuda.current_stream(self.device).cuda_stream
-            rc = lib.hispmv_boundary_pack(self._d_last.data_ptr(), self.tail_mask.data_ptr(), self.send.data_ptr(), self.n, self._stream)
-            if rc != 0:
-                raise RuntimeError(f"hispmv_boundary_pack failed ({rc})")
+                self._stream = self._pick_stream()
+            self.fpga.boundary_pack(self._d_last.data_ptr(), self.tail_mask.data_ptr(), self.send.data_ptr(), self.n, self._stream)
             return
         last = torch.stack([m["y"][-1] if ok else self.zero for m, ok in zip(mats, self.has_rows)])
         torch.mul(last, self.tail_mask, out=self.send)
@@ -239,10 +246,7 @@ class BoundaryExchange:
     def apply(self, mats) -> None:
         """Second half: self.recv (every rank's tails) -> the chain of this rank's first rows, added in rank order."""
         if self.send.is_cuda:
-            from ._lib import lib
-            rc = lib.hispmv_boundary_apply(self._d_first.data_ptr(), self.recv.data_ptr(), self._w.data_ptr(), self.n, self.world, self._stream)
-            if rc != 0:
-                raise RuntimeError(f"hispmv_boundary_apply failed ({rc})")
+            self.fpga.boundary_apply(self._d_first.data_ptr(), self.recv.data_ptr(), self._w.data_ptr(), self.n, self.world, self._stream)
             return
         if self.heads:
             incoming = (self.recv.view(self.world, self.n).t() * self.weights).sum(dim=1)
@@ -268,13 +272,14 @@ class LoopbackWorld:
     process-per-GPU path, without a process group.  For checking the sharded path at world sizes a one-GPU box cannot
     host as processes (tests/test_gpu_dist_full.py: world 8)."""
 
-    def __init__(self, per_rank_mats, device):
+    def __init__(self, per_rank_mats, device, fpgas=None, stream: int | None = None):
         import torch
         self.torch = torch
         self.world = len(per_rank_mats)
         self.mats = per_rank_mats
         n = len(per_rank_mats[0])
-        self.ex = [BoundaryExchange(n, device, world=self.world, rank=r) for r in range(self.world)]
+        # fpgas: one FpgaHandle per virtual rank (GPU runs: the context whose SpMVs fill that rank's y vectors)
+        self.ex = [BoundaryExchange(n, device, world=self.world, rank=r, fpga=fpgas[r] if fpgas else None, stream=stream) for r in range(self.world)]
         flags = [e.local_flags(m) for e, m in zip(self.ex, per_rank_mats)]
         allf = np.stack(flags)
         for e, m, f in zip(self.ex, per_rank_mats, flags):

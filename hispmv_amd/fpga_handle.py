@@ -196,6 +196,15 @@ class FpgaHandle:
             raise RuntimeError(self._err() or "time_device failed")
         return float(ms)
 
+    def boundary_pack(self, d_last: int, d_mask: int, d_send: int, n: int, stream: int = 0) -> None:
+        """send[i] = mask[i] * *last[i] (hispmv_boundary_pack); `stream` 0 = the context's stream, as for spmv_device."""
+        self._check(lib.hispmv_boundary_pack(self._ctx, C.c_void_p(d_last), C.c_void_p(d_mask), C.c_void_p(d_send), int(n), C.c_void_p(stream)))
+
+    def boundary_apply(self, d_first: int, d_recv: int, d_weights: int, n: int, world: int, stream: int = 0) -> None:
+        """*first[i] += sum_r recv[r*n + i] * weights[i*world + r] (hispmv_boundary_apply); `stream` 0 = the context's stream."""
+        self._check(lib.hispmv_boundary_apply(self._ctx, C.c_void_p(d_first), C.c_void_p(d_recv), C.c_void_p(d_weights), int(n), int(world),
+                                              C.c_void_p(stream)))
+
     def synchronize(self) -> None:
         self._check(lib.hispmv_synchronize(self._ctx))
 

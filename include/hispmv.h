@@ -96,7 +96,10 @@ int hispmv_linear(hispmv_ctx* ctx, int matrix_idx, const float* x, int64_t x_len
 
 /* ---- device-resident entry points (no counterpart in the reference, whose vectors always cross
  * PCIe -- fpga_handle.cpp:306-320).  d_* are device pointers; the launch is asynchronous on
- * `stream` (a hipStream_t, NULL = the context's stream).  Used by bench.py and the multi-GPU driver. */
+ * `stream` (a hipStream_t).  ONE rule for every entry point that takes a stream (hispmv_spmv_device, hispmv_spmv_device_batch,
+ * hispmv_boundary_pack, hispmv_boundary_apply): NULL = the context's own stream (created non-blocking: it does NOT synchronise
+ * with HIP's null stream), anything else = the caller's stream.  Work issued with NULL is ordered with other NULL work of the
+ * same context; hispmv_synchronize waits for it.  Used by bench.py and the multi-GPU driver. */
 int hispmv_spmv_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, const float* d_bias, float* d_y,
                        float alpha, float beta, void* stream);
 /* Waits for the context's stream and for the last caller-supplied stream a launch of this context went to, then reports
@@ -135,9 +138,10 @@ float hispmv_time_device(hispmv_ctx* ctx, int matrix_idx, const float* d_x, cons
  * tails that feeds its first row.  These two launches are the device side of that step on `stream`:
  *   pack:  send[i] = mask[i] * *last[i]                                   (last[i] may be NULL: 0)
  *   apply: *first[i] += sum_r recv[r*n + i] * weights[i*world + r]        (first[i] NULL: nothing), r ascending
- * All pointers are device pointers (last/first: device arrays of n device pointers). */
-int hispmv_boundary_pack(const float* const* d_last, const float* d_mask, float* d_send, int32_t n, void* stream);
-int hispmv_boundary_apply(float* const* d_first, const float* d_recv, const float* d_weights, int32_t n, int32_t world,
+ * All pointers are device pointers (last/first: device arrays of n device pointers).  `stream` as everywhere in this header:
+ * NULL = the context's stream, so SpMVs and boundary kernels issued with NULL run on one queue, in order. */
+int hispmv_boundary_pack(hispmv_ctx* ctx, const float* const* d_last, const float* d_mask, float* d_send, int32_t n, void* stream);
+int hispmv_boundary_apply(hispmv_ctx* ctx, float* const* d_first, const float* d_recv, const float* d_weights, int32_t n, int32_t world,
                           void* stream);
 
 /* ---- getters (HiSpmvHandle getters, spmv-helper.cpp:752-810) ------------------------------------ */

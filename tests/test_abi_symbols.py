@@ -47,10 +47,10 @@ def test_device_entry_points_check_their_arguments_before_touching_the_device():
     lib = _lib.lib
     assert lib.hispmv_spmv_device_batch(None, 0, None, None, None, None, 1.0, 1.0, None) == _lib.HISPMV_EINVAL
     assert lib.hispmv_spmv_device(None, 0, None, None, None, 1.0, 1.0, None) == _lib.HISPMV_EINVAL
-    assert lib.hispmv_boundary_pack(None, None, None, -1, None) == _lib.HISPMV_EINVAL
-    assert lib.hispmv_boundary_pack(None, None, None, 3, None) == _lib.HISPMV_EINVAL
-    assert lib.hispmv_boundary_apply(None, None, None, 3, 2, None) == _lib.HISPMV_EINVAL
-    assert lib.hispmv_boundary_apply(None, None, None, 0, 0, None) == _lib.HISPMV_EINVAL      # world < 1
+    assert lib.hispmv_boundary_pack(None, None, None, None, -1, None) == _lib.HISPMV_EINVAL      # no context
+    assert lib.hispmv_boundary_pack(None, None, None, None, 3, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_boundary_apply(None, None, None, None, 3, 2, None) == _lib.HISPMV_EINVAL
+    assert lib.hispmv_boundary_apply(None, None, None, None, 0, 0, None) == _lib.HISPMV_EINVAL
     assert lib.hispmv_synchronize(None) == _lib.HISPMV_EINVAL
 
 

@@ -185,3 +185,47 @@ def test_virtual_ranks_loopback_world(world):
         assert (cover == 1).all(), "every row has exactly one owner"
         y64, mag = oracle.spmv_f64(m["rp"], m["ci"], m["va"], m["x"], m["b"], alpha, beta)
         assert bwd_err(y, y64, mag) < 1e-5
+
+
+def test_rank_breakdown_summary_and_host_threads_per_rank():
+    """bench.py's `rank_breakdown`: min / max / mean over ranks, the rank holding the maximum, the imbalance
+    figure; and the per-rank share of the host CPUs (quota / LOCAL_WORLD_SIZE)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    per_rank = [dict(rank=1, batch_us=300.0, exchange_us=14.0, step_us_eager=314.0, nnz=100, rows=10, formats={"slices/1024t": 3}, host_threads=2, prep_upload_s=1.0),
+                dict(rank=0, batch_us=200.0, exchange_us=18.0, step_us_eager=218.0, nnz=120, rows=12, formats={"slices/1024t": 3}, host_threads=2, prep_upload_s=1.5)]
+    out = bench.summarize_ranks(per_rank)
+    assert out["ranks"] == 2 and [q["rank"] for q in out["per_rank"]] == [0, 1]
+    assert out["batch_us"] == {"min": 200.0, "max": 300.0, "mean": 250.0, "argmax_rank": 1}
+    assert out["exchange_us"]["argmax_rank"] == 0 and out["nnz"]["max"] == 120
+    assert out["batch_imbalance_max_over_mean"] == 1.2
+    one = bench.summarize_ranks([dict(rank=0, batch_us=290.0, exchange_us=None, step_us_eager=290.0, nnz=5, rows=1, formats={}, host_threads=None, prep_upload_s=0.1)])
+    assert "exchange_us" not in one and one["batch_us"]["mean"] == 290.0
+    n1, n8 = bench.host_threads_per_rank(1), bench.host_threads_per_rank(8)
+    assert n1 >= 1 and n8 == max(1, n1 // 8)
+
+
+def test_host_threads_are_private_to_the_library():
+    """creating handles must not change the process-global OpenMP setting; HISPMV_HOST_THREADS sets the library's own
+    count (bench.py --gpus N: quota / LOCAL_WORLD_SIZE per rank).  In a child process: the count is decided once per process."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = ("import os, ctypes; os.environ['HISPMV_HOST_THREADS'] = '3'\n"
+            "import numpy as np\n"
+            "from hispmv_amd._lib import lib\n"
+            "from hispmv_amd.prep import prep_from_coo\n"
+            "gomp = ctypes.CDLL('libgomp.so.1'); before = gomp.omp_get_max_threads()\n"
+            "r = np.arange(5000, dtype=np.int32) % 100; c = np.arange(5000, dtype=np.int32) % 77\n"
+            "p = prep_from_coo(r, c, np.ones(5000, np.float32), 100, 77)\n"
+            "assert p.nnz == 5000\n"
+            "print(lib.hispmv_host_threads(), before, gomp.omp_get_max_threads())\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(root), timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    mine, before, after = (int(v) for v in out.stdout.split()[-3:])
+    assert mine == 3 and before == after

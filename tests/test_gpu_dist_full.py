@@ -103,7 +103,7 @@ def _virtual_ranks(world, shards_of, mats, steps=2):
     fpga.load_matrices()
     batches = [fpga.prepare_batch([e["idx"] for e in loc], [e["x"].data_ptr() for e in loc], [e["b"].data_ptr() for e in loc],
                                   [e["y"].data_ptr() for e in loc]) for loc in per_rank]
-    lw = LoopbackWorld(per_rank, dev)
+    lw = LoopbackWorld(per_rank, dev, fpgas=[fpga] * world)
     # one explicit (non-default) stream for the SpMVs and the boundary kernels, as bench.py does: a stream handle of 0
     # means "the context's own stream" to the library, which the boundary kernels on the default stream would not wait for
     side = torch.cuda.Stream(device=dev)
@@ -156,7 +156,7 @@ def _worker(rank, world, port, tmp, names, out_q):
     torch.cuda.set_stream(stream)
     batch = fpga.prepare_batch([e["idx"] for e in local], [e["x"].data_ptr() for e in local], [e["b"].data_ptr() for e in local],
                                [e["y"].data_ptr() for e in local])
-    ex = BoundaryExchange(len(local), dev)
+    ex = BoundaryExchange(len(local), dev, fpga=fpga)
     ex.prepare(local)
     for _ in range(2):
         fpga.spmv_device_batch(batch, ALPHA, BETA, stream.cuda_stream)
