@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "hispmv_choose.h"
 #include "hispmv_kernels.h"
 #include "hispmv_plan.h"
 #include "hispmv_prep.h"
@@ -42,15 +43,9 @@ struct Matrix {
     // are scattered -- one stream per COLUMN TILE (the reference's column tiling, tileAndPad
     // spmv-helper.cpp:242-263, with L2 in the role of the BRAM x window): part 0 computes
     // y = alpha*A0*x + beta*bias, part t > 0 accumulates y = alpha*At*x + 1*y.
-    struct Part {
-        SliceStream st;                            // host side (released after upload)
-        std::vector<FixEntry> fix_short, fix_long;
-        LaunchPlan plan;
-        DeviceStream dstream;                      // the planned stream in its device layout (compact / wide groups)
-        bool is_tts = false;                       // the part is a transposed tile stream (hispmv_tts.h) instead of a slice stream
-        TtsStream tts;                             //   host side (released after upload)
-        TtsDeviceMatrix tdev;                      //   device side
-        SpmvDeviceMatrix dev;                      // device side
+    struct Part : HostPart {                       // host side (hispmv_choose.h; released after upload) + device side
+        TtsDeviceMatrix tdev;                      //   of a tile stream
+        SpmvDeviceMatrix dev;                      //   of a slice stream
     };
     std::vector<Part> parts;
     std::vector<float> dense_host;
@@ -100,7 +95,6 @@ struct hispmv_ctx {
     int64_t arena_budget = 0, arena_used = 0;
     float *d_x = nullptr, *d_y = nullptr;     // device vectors of run_kernel / linear: [x | bias] and y
     int64_t cap_x = 0, cap_y = 0;
-    int64_t col_tile_bytes = 4 << 20;   // x bytes per column tile for scattered matrices (HISPMV_COL_TILE_BYTES)
     int* h_err = nullptr;        // pinned, device-mapped word set by a kernel whose bounded carry wait expired
     int* d_err = nullptr;        //   (its device address): read on the host after a stream sync, no copy
     // run_kernel / linear with host vectors: x and bias are gathered in one pinned block and go up in ONE copy, y comes
@@ -159,11 +153,9 @@ struct hispmv_ctx {
     // device format of matrices whose plan gathers x through L2: 0 slice stream always, 1 transposed tile stream whenever
     // the plan has no window, 2 auto = transposed tile stream when its gathers touch <= 32 cache lines of x per wave
     // instruction (HISPMV_FORMAT=slices|tts|auto)
-    int format_mode = 2;
+    FormatOptions format_opts;   // HISPMV_FORMAT / _TTS_GEOMETRY / _BAND_TILES / _COL_TILE_BYTES / _TTS_MIN_NNZ (hispmv_choose.h)
     // geometry of a transposed tile stream: 0 the 8 K-row tiles always, 1 the tall geometry (two column parts of 16 K-row
     // tiles) for every tile stream, 2 auto (HISPMV_TTS_GEOMETRY=standard|tall|auto)
-    bool band_tiles = true;      // HISPMV_BAND_TILES=0: no diagonal-relative tiles for wide-band matrices
-    int tts_geometry = 0;        // default: standard (measured: neither of the others is faster on soc-Pokec)
     int n_cus = 256;
 };
 
@@ -252,91 +244,9 @@ int ensure_vec(hispmv_ctx* c, float** p, int64_t* cap, int64_t n) {
     return HISPMV_OK;
 }
 
-// Column range [c0, c1) of a CSR matrix as its own CSR (global column ids are kept: x is shared).
-Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
-    Csr t;
-    t.rows = m.rows; t.cols = m.cols;
-    t.row_ptr.assign((size_t)m.rows + 1, 0);
-#pragma omp parallel for num_threads(host_threads()) schedule(static)
-    for (int32_t i = 0; i < m.rows; ++i) {
-        const int32_t* b = m.col.data() + m.row_ptr[i];
-        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
-        t.row_ptr[(size_t)i + 1] = std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0);
-    }
-    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
-    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
-#pragma omp parallel for num_threads(host_threads()) schedule(static)
-    for (int32_t i = 0; i < m.rows; ++i) {
-        const int32_t* b = m.col.data() + m.row_ptr[i];
-        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
-        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
-        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
-        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
-        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
-    }
-    return t;
-}
-
-// Offsets [o0, o1) from the (scaled) diagonal of a CSR matrix as its own CSR: row i keeps its columns in
-// [i*cols/rows + o0, i*cols/rows + o1) (global column ids are kept: x is shared).  open_lo / open_hi: no lower / upper bound.
-Csr band_tile(const Csr& m, int64_t o0, int64_t o1, bool open_lo, bool open_hi) {
-    Csr t;
-    t.rows = m.rows; t.cols = m.cols;
-    t.row_ptr.assign((size_t)m.rows + 1, 0);
-    auto bounds = [&](int32_t i, int32_t& c0, int32_t& c1) {
-        const int64_t cen = (int64_t)i * m.cols / m.rows;
-        c0 = open_lo ? 0 : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o0));
-        c1 = open_hi ? m.cols : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o1));
-    };
-#pragma omp parallel for num_threads(host_threads()) schedule(static)
-    for (int32_t i = 0; i < m.rows; ++i) {
-        int32_t c0, c1; bounds(i, c0, c1);
-        const int32_t* b = m.col.data() + m.row_ptr[i];
-        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
-        t.row_ptr[(size_t)i + 1] = c1 > c0 ? std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0) : 0;
-    }
-    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
-    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
-#pragma omp parallel for num_threads(host_threads()) schedule(static)
-    for (int32_t i = 0; i < m.rows; ++i) {
-        int32_t c0, c1; bounds(i, c0, c1);
-        const int32_t* b = m.col.data() + m.row_ptr[i];
-        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
-        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
-        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
-        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
-        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
-    }
-    return t;
-}
-
-// Width (in columns) of a column tile; 0 = no tiling.  Tiling applies only when the plan of the whole
-// matrix gathers x through L2 (no LDS window) and x exceeds `tile_bytes` (default 4 MiB = one XCD's
-// L2, i.e. tiles of 2-4 MiB; HISPMV_COL_TILE_BYTES overrides, 0 disables).
-int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
-    if (tile_bytes <= 0 || (int64_t)cols * 4 <= tile_bytes + tile_bytes / 2) return 0;
-    // 2, 4 or 8 tiles: in a batch call the tiles of a matrix run in the same round, each pinned to 8 / tiles of the
-    // 8 XCDs, so that an XCD's L2 holds one tile's part of x (more than 8 tiles' worth of x: 8 larger tiles)
-    int64_t tiles = ((int64_t)cols * 4 + tile_bytes - 1) / tile_bytes;
-    tiles = tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
-    const int64_t w = (((int64_t)cols + tiles - 1) / tiles + 63) & ~63LL;     // equal tiles, 256-byte aligned
-    return (int32_t)w;
-}
-
-// The launch plan of a part, then its device layout.  Two steps: a matrix that becomes a tile stream needs the plan (the
-// decision reads it) but not the device layout of the slice stream it drops (0.14 s on soc-Pokec's shape).
-void plan_part(Matrix::Part& p, int n_cus) {
-    for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
-    p.plan = make_plan(p.st, n_cus);     // also rewrites the column field of LDS-staged groups
-}
-void pack_part(Matrix::Part& p) {
-    p.dstream = pack_device_stream(p.st, p.plan);
-    p.st.words = WordVec();   // the device layout replaces the host words
-}
-void finish_part(Matrix::Part& p, int n_cus) { plan_part(p, n_cus); pack_part(p); }
-
 // Registers a prepared sparse matrix with the context (capacity check = the reference's
-// "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).
+// "offset + size > MAX_BUFFER_SIZE_BYTES -> return -1", fpga_handle.cpp:192-195).  The format and tiling decision itself is
+// host-only code: choose_format (hispmv_choose.cpp).
 int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
     // HISPMV_PREP_TRACE=1: the phases of the host side of preprocessing on stderr (diagnostics)
@@ -352,265 +262,29 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
                             c->last_prep_times.stream_device * 1e3, c->last_prep_times.download * 1e3);
     auto m = std::make_unique<Matrix>();
     m->rows = csr.rows; m->cols = csr.cols; m->nnz = csr.nnz();
-    m->parts.emplace_back();
-    m->parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
-    lap("slice stream (host) / adopt");
-    plan_part(m->parts[0], c->n_cus);            // (its device layout: once the format is decided, below)
-    lap("launch plan");
-    bool whole_packed = false;
-    // Column tiling when the whole-matrix plan has to gather x through L2:
-    //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
-    //  * x larger than an XCD's L2: L2-sized tiles.
-    int32_t tw = 0, tbase = 0;
-    const LaunchPlan& whole = m->parts[0].plan;
-    // columns the matrix actually uses: a block of a larger matrix (a rank's shard: x is replicated at full length)
-    // is tiled over ITS column range, not over the width of x; the 0.1 % of elements at either end do not count
-    // (a shard also holds a few rows of the next block) -- they go to the first / last tile, which are open-ended
-    int32_t cmin = INT32_MAX, cmax = -1;
-    const int64_t nnz_all = csr.nnz();
-#pragma omp parallel for num_threads(host_threads()) reduction(min : cmin) reduction(max : cmax) schedule(static)
-    for (int64_t k = 0; k < nnz_all; ++k) { cmin = std::min(cmin, csr.col[(size_t)k]); cmax = std::max(cmax, csr.col[(size_t)k]); }
-    if (cmax >= cmin) {
-        // (bins of 2^shift columns, at most 1024 of them; every 4th entry of a large matrix: the cut is a 0.1 % quantile.
-        // A 64-bit division per entry made this pass 44 ms on soc-Pokec's shape.)
-        constexpr int kBins = 1024;
-        int shift = 0;
-        while ((((int64_t)cmax - cmin) >> shift) >= kBins) ++shift;
-        const int64_t bin_w = 1ll << shift;
-        const int64_t stride = nnz_all >= (4 << 20) ? 4 : 1;
-        std::vector<int64_t> hist(kBins, 0);
-#pragma omp parallel num_threads(host_threads())
-        {
-            std::vector<int64_t> local(kBins, 0);
-#pragma omp for schedule(static) nowait
-            for (int64_t k = 0; k < nnz_all; k += stride) local[(size_t)((uint32_t)(csr.col[(size_t)k] - cmin) >> shift)] += stride;
-#pragma omp critical
-            for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
-        }
-        const int64_t cut = nnz_all / 1000;
-        int lo = 0, hi = kBins - 1;
-        for (int64_t acc = 0; lo < hi && acc + hist[(size_t)lo] <= cut; ++lo) acc += hist[(size_t)lo];
-        for (int64_t acc = 0; hi > lo && acc + hist[(size_t)hi] <= cut; --hi) acc += hist[(size_t)hi];
-        const int64_t qlo = cmin + lo * bin_w, qhi = std::min<int64_t>(cmax, cmin + (hi + 1) * bin_w - 1);
-        cmin = (int32_t)qlo; cmax = (int32_t)qhi;
+    FormatChoice ch = choose_format(std::move(csr), prebuilt, c->n_cus, c->format_opts, lap);
+    m->format = ch.format; m->tile_kind = ch.tile_kind; m->col_tile_width = ch.col_tile_width; m->col_tile_base = ch.col_tile_base;
+    m->l2_tiles = ch.l2_tiles; m->tts_lines_per_gather = ch.tts_lines_per_gather;
+    for (HostPart& hp : ch.parts) {
+        m->parts.emplace_back();
+        static_cast<HostPart&>(m->parts.back()) = std::move(hp);
     }
-    const int32_t used = cmax >= cmin ? cmax - (cmin & ~63) + 1 : 0;
-    // Scattered columns (no window pays): the transposed tile stream, when sorting a row tile's elements by column brings
-    // several of them onto each cache line of x (hispmv_tts.h).  Takes the place of the L2-sized column tiles below.
-    // (from 1 M entries: a tile is a long latency chain -- column-order pass, barrier, row-order pass per block --, the
-    // smallest matrices of the benchmark set run faster as slice streams: three alternating rounds, step of the set with
-    // two launch streams, threshold 64 K: 342-345 us, 1 M: 342-346 us, 4 M: 352-355 us; matrices alone: trans5 16.7 vs 10.1 us)
-    int64_t tts_min = 1 << 20;
-    if (const char* env = std::getenv("HISPMV_TTS_MIN_NNZ")) tts_min = std::atoll(env);       // experiments
-    // Candidates: plans without a window, and plans whose window leaves more than 5 % of the gathers to L2 (a wide band
-    // without column reuse between rows: the pessimistic stand-ins of PFlow_742 / Si41Ge41H72, 86 and 69 us with a 128 KiB
-    // window of the most used blocks) -- there the two formats are compared by their L2 requests per element.
-    const int64_t all_elems = m->parts[0].st.n_slices * (int64_t)kSliceElems;
-    const double slice_requests = whole.lds_floats == 0 ? 1.0
-                                 : ((double)whole.global_elems + (double)whole.staged_floats / kFragBlock) / (double)std::max<int64_t>(all_elems, 1);
-    // (x at most two windows wide is cut into two column tiles that each run from LDS: mouse_gene 56 us that way, 77 us as
-    // a tile stream)
-    const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096;
-    const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
-    // (x of at most 256 KiB stays in L1 / L2 whatever the order of the gathers: the slice stream's per-element gathers are cheap
-    // there and a tile is a longer latency chain -- the 1024 x 8192 layer of apps/model_test.py: 10.0 us as a slice stream
-    // against 15.0 us as a tile stream, 8 vectors through `linear` 33 against 58 us.  Not 1 MiB: Si41Ge41H72 as an
-    // unstructured band, 742 KB of x, is 39.5 us as a tile stream and 45 as a slice stream; the pessimistic family's step
-    // 0.329 -> 0.363 ms with that threshold.)
-    const bool x_is_small = (int64_t)used * 4 <= (256 << 10);
-    // BAND TILES: a banded matrix whose band is wider than an LDS window -- every group of rows touches band + rows columns --
-    // is cut along the DIAGONAL: part t holds the elements whose offset from the (scaled) diagonal lies in the t-th of P equal
-    // ranges of the band.  A group of a part then touches (band / P + its rows) columns: a window that fits, every element in
-    // it, 6-byte elements from LDS instead of per-element gathers through the cache -- the reference's column tiling
-    // (tileAndPad spmv-helper.cpp:242-263) in the coordinates of a band.  Part 0 writes y, the others partial vectors that
-    // the tail launch merges; all parts share one grid.  (PFlow_742 as an unstructured band +-20000: 82 us as a tile stream.)
-    if (candidate && c->band_tiles && c->format_mode != 1 && nnz_all >= (4 << 20) && csr.rows > 1 && !x_is_small) {
-        constexpr int kBins = 4096;
-        const int64_t span = (int64_t)csr.cols + csr.rows;            // offsets lie in (-cols, cols)
-        int shift = 0;
-        while ((2 * span >> shift) >= kBins) ++shift;
-        std::vector<int64_t> hist(kBins, 0);
-#pragma omp parallel num_threads(host_threads())
-        {
-            std::vector<int64_t> local(kBins, 0);
-#pragma omp for schedule(static) nowait
-            for (int32_t i = 0; i < csr.rows; ++i) {
-                const int64_t cen = (int64_t)i * csr.cols / csr.rows;
-                for (int64_t k = csr.row_ptr[i]; k < csr.row_ptr[(size_t)i + 1]; ++k) local[(size_t)((csr.col[(size_t)k] - cen + span) >> shift)]++;
-            }
-#pragma omp critical
-            for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
-        }
-        const int64_t cut = nnz_all / 1000;
-        int lo = 0, hi = kBins - 1;
-        for (int64_t acc = 0; lo < hi && acc + hist[(size_t)lo] <= cut; ++lo) acc += hist[(size_t)lo];
-        for (int64_t acc = 0; hi > lo && acc + hist[(size_t)hi] <= cut; --hi) acc += hist[(size_t)hi];
-        const int64_t dmin = ((int64_t)lo << shift) - span, dmax = (((int64_t)hi + 1) << shift) - span - 1;
-        const int64_t W = dmax - dmin + 1;
-        constexpr int64_t kTarget = 20 * 1024;                        // offsets per part: leaves ~12 K floats of window for the rows of a group
-        lap("band histogram");
-        if (W > kTarget && W <= 8 * kTarget && W < (int64_t)used) {
-            const int P = (int)((W + kTarget - 1) / kTarget);
-            const int64_t width = (((W + P - 1) / P) + 63) & ~63LL;
-            std::vector<Matrix::Part> parts;
-            bool ok = true;
-            for (int t = 0; t < P && ok; ++t) {
-                Csr tile = band_tile(csr, dmin + t * width, dmin + (t + 1) * width, t == 0, t == P - 1);
-                parts.emplace_back();
-                parts.back().st = build_stream(tile);
-                finish_part(parts.back(), std::max(1, c->n_cus / P));
-                const Matrix::Part& q = parts.back();
-                ok = q.plan.lds_floats > 0 && q.plan.global_elems * 50 <= q.st.n_slices * (int64_t)kSliceElems;
-            }
-            lap("band tiles");
-            if (ok) {
-                m->parts = std::move(parts);
-                m->tile_kind = 2; m->col_tile_width = (int)width; m->col_tile_base = (int)dmin;
-                csr = Csr{};
-                for (auto& p : m->parts) {
-                    m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
-                    m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
-                    m->compact_slices += p.dstream.compact_slices;
-                }
-                m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of parts t > 0
-                m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
-                m->plan_lds = m->parts[0].plan.lds_floats;
-                m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
-                c->arena_used += m->device_bytes;
-                m->index = (int)c->mats.size();
-                c->mats.push_back(std::move(m));
-                return (int)c->mats.size() - 1;
-            }
-        }
-    }
-    if (candidate && c->format_mode != 0 && ((nnz_all >= tts_min && !x_is_small) || (c->format_mode == 1 && nnz_all >= 64 * 1024))) {
-        lap("column range / histogram");
-        TtsGeometry g0;
-        g0.zero_fill = c->tts_geometry == 4;        // HISPMV_TTS_GEOMETRY=zerofill: the standard sizes, no filler words (experiment)
-        TtsStream ts = build_tts(csr, 0, g0);
-        lap("tile stream packer");
-        if (ts.lines_per_gather <= 8.0 && std::getenv("HISPMV_TTS_SMALL")) {
-            // experiment (off by default: measured slower): cheap gathers -> the half-LDS geometry, two workgroups per CU
-            TtsGeometry small;
-            small.max_slots = kTtsSmallSlots; small.max_rows = kTtsSmallRows; small.tiles_wanted = 512;
-            TtsStream t2 = build_tts(csr, 0, small);
-            if (t2.lines_per_gather <= 16.0) ts = std::move(t2);
-        }
-        // (a tile is one workgroup's work; the packer cuts rows longer than a tile and a quarter into pieces and orders
-        // the tiles longest first, so this only rejects what is left: tiles capped by their row count next to full ones)
-        const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
-        const bool fewer_requests = ts.lines_per_gather / 64.0 + 0.1 < slice_requests;     // (+0.1: the two passes and barriers of a block)
-        if (c->format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced && fewer_requests)) {
-            // The TALL geometry (hispmv_tts.h): when a gather of the 8 K-row tiles still touches many lines of x and x is
-            // larger than an XCD's L2, the matrix becomes two column parts of 16 K-row tiles -- the same number of tiles
-            // and elements per tile over half the column range (soc-Pokec: 23 -> 13 lines per gather), and in a batch
-            // call each part is pinned to four XCDs whose L2s then hold its half of x.  HISPMV_TTS_GEOMETRY=standard|tall|paired|auto
-            // (standard is the default: the gathers are bound by the cache's accesses per element, not by lines -- DESIGN.md 2.2).
-            std::vector<TtsStream> tall;
-            const bool paired = c->tts_geometry == 3;
-            const bool want_tall = c->tts_geometry == 1 || paired ||
-                                   (c->tts_geometry == 2 && ts.lines_per_gather > 16.0 && (int64_t)used * 4 > (4 << 20) && csr.rows >= 64 * kTtsTallRows);
-            if (want_tall) {
-                const std::vector<int32_t> cuts = tts_column_cuts(csr, kTtsTallParts);
-                double lines = 0; int64_t slices = 0;
-                bool ok = true;
-                for (int q = 0; q < kTtsTallParts && ok; ++q) {
-                    Csr part = csr_column_range(csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? csr.cols : cuts[(size_t)q]);
-                    tall.push_back(build_tts(part, 0, paired ? tts_paired_geometry(c->n_cus) : tts_tall_geometry(c->n_cus, kTtsTallParts)));
-                    const TtsStream& t = tall.back();
-                    lines += t.lines_per_gather * (double)t.col_base.size(); slices += (int64_t)t.col_base.size();
-                    ok = t.max_tile_slots <= 2 * (t.total_slots / std::max<int64_t>(1, (int64_t)t.tiles.size())) + 4096;
-                }
-                // (auto: only when it pays -- at least a quarter fewer lines per gather)
-                if (!ok || (c->tts_geometry == 2 && lines / (double)std::max<int64_t>(slices, 1) > 0.75 * ts.lines_per_gather)) tall.clear();
-            }
-            m->format = 1;
-            if (!tall.empty()) {
-                m->parts.clear();
-                double lines = 0;
-                for (TtsStream& t : tall) {
-                    m->parts.emplace_back();
-                    Matrix::Part& p = m->parts.back();
-                    p.is_tts = true;
-                    lines += t.lines_per_gather * (double)t.col_base.size();
-                    m->n_slices += (int64_t)t.col_base.size(); m->n_elems += t.nnz + t.n_fillers; m->n_split += (int64_t)t.fix.size() / 4;
-                    m->device_bytes += t.bytes();
-                    p.tts = std::move(t);
-                }
-                m->tts_lines_per_gather = lines / (double)std::max<int64_t>(m->n_slices, 1);
-                m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;     // partial vectors of parts t > 0
-                m->col_tile_width = tts_column_cuts(csr, kTtsTallParts)[0];
-            } else {
-                Matrix::Part& p = m->parts[0];
-                p.is_tts = true;
-                p.tts = std::move(ts);
-                p.st = SliceStream{}; p.dstream = DeviceStream{}; p.fix_short = {}; p.fix_long = {};
-                m->tts_lines_per_gather = p.tts.lines_per_gather;
-                m->n_slices = (int64_t)p.tts.col_base.size(); m->n_elems = m->nnz + p.tts.n_fillers; m->n_split = (int64_t)p.tts.fix.size() / 4;
-                m->device_bytes = p.tts.bytes();
-            }
-            m->plan_threads = m->parts[0].tts.geometry.threads; m->plan_group = m->parts[0].tts.geometry.max_slots / kTtsChunk; m->plan_lds = 0;
-            m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            csr = Csr{};
-            if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
-            c->arena_used += m->device_bytes;
-            m->index = (int)c->mats.size();
-    c->mats.push_back(std::move(m));
-            return (int)c->mats.size() - 1;
-        }
-    }
-    // (a window that leaves more than a tenth of the gathers to L2 counts as "does not fit" here)
-    const bool spilling = whole.lds_floats > 0 && whole.global_elems * 10 > m->parts[0].st.n_slices * (int64_t)kSliceElems;
-    if (used > 0 && (whole.lds_floats == 0 || spilling)) {
-        if (used <= 2 * kMaxLdsFloats && c->col_tile_bytes > 0 && m->parts[0].st.n_slices >= 4096)
-            tw = ((used + 1) / 2 + 63) & ~63;
-        else if (whole.lds_floats == 0) tw = column_tile_width(used, c->col_tile_bytes);
-        tbase = cmin & ~63;
-    }
-    if (tw > 0) {
-        m->col_tile_width = tw; m->col_tile_base = tbase; m->tile_kind = 1;
-        m->parts.clear();
-        for (int64_t c0 = tbase; c0 <= cmax; c0 += tw) {
-            const bool first = c0 == tbase, last = c0 + tw > cmax;           // the end tiles are open-ended
-            Csr tile = column_tile(csr, first ? 0 : (int32_t)c0, last ? csr.cols : (int32_t)(c0 + tw));
-            m->parts.emplace_back();
-            m->parts.back().st = build_stream(tile);
-            // the tiles of a matrix run in one grid: a two-window tile (resident plan: one long chunk per workgroup, its x
-            // window staged once) is planned for its share of the CUs
-            const int n_tiles = (int)((cmax - tbase) / tw + 1);
-            finish_part(m->parts.back(), used <= 2 * kMaxLdsFloats ? std::max(1, c->n_cus / std::max(1, n_tiles)) : c->n_cus);
-        }
-        // two tiles were meant to bring the x window into LDS: if they still gather through L2, tiling only
-        // costs a launch and a read-modify-write of y -- go back to the single stream
-        bool lds_goal = used <= 2 * kMaxLdsFloats, all_lds = true;
-        for (auto& p : m->parts)
-            all_lds = all_lds && p.plan.lds_floats > 0 && p.plan.global_elems * 50 <= p.st.n_slices * (int64_t)kSliceElems;
-        if ((lds_goal && !all_lds) || m->parts.size() < 2) {
-            m->parts.clear();
-            m->col_tile_width = 0; m->col_tile_base = 0; m->tile_kind = 0;
-            m->parts.emplace_back();
-            m->parts[0].st = build_stream(csr);
-            finish_part(m->parts[0], c->n_cus);
-        } else if (!lds_goal) {
-            const size_t np = m->parts.size();
-            bool same = np == 2 || np == 4 || np == 8;
-            for (auto& p : m->parts) same = same && p.plan.block_threads == m->parts[0].plan.block_threads && p.plan.lds_floats == 0;
-            m->l2_tiles = same;
-        }
-    }
-    csr = Csr{};
-    lap("column tiles (if any)");
-    if (!whole_packed && tw == 0) pack_part(m->parts[0]);       // the whole-matrix stream stays: its device layout now
-    lap("device layout");
     for (auto& p : m->parts) {
-        m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
-        m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
-        m->compact_slices += p.dstream.compact_slices;
+        if (p.is_tts) {
+            m->n_slices += (int64_t)p.tts.col_base.size(); m->n_elems += p.tts.nnz + p.tts.n_fillers; m->n_split += (int64_t)p.tts.fix.size() / 4;
+            m->device_bytes += p.tts.bytes();
+        } else {
+            m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
+            m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
+            m->compact_slices += p.dstream.compact_slices;
+        }
     }
-    if (m->parts.size() > 1) m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of tiles t > 0
-    m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices;
-    m->plan_lds = m->parts[0].plan.lds_floats;
+    if (m->parts.size() > 1) m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of parts t > 0
+    if (m->format == 1) {
+        m->plan_threads = m->parts[0].tts.geometry.threads; m->plan_group = m->parts[0].tts.geometry.max_slots / kTtsChunk; m->plan_lds = 0;
+    } else {
+        m->plan_threads = m->parts[0].plan.block_threads; m->plan_group = m->parts[0].plan.group_slices; m->plan_lds = m->parts[0].plan.lds_floats;
+    }
     m->prep_seconds = t_csr + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (c->arena_used + m->device_bytes > c->arena_budget) return HISPMV_FULL;
     c->arena_used += m->device_bytes;
@@ -795,7 +469,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if ((e = hipHostMalloc((void**)&c->h_err, sizeof(int), hipHostMallocMapped)) != hipSuccess) return give_up(e, "hipHostMalloc(err flag)");
     *c->h_err = 0;
     if ((e = hipHostGetDevicePointer((void**)&c->d_err, c->h_err, 0)) != hipSuccess) return give_up(e, "hipHostGetDevicePointer(err flag)");
-    if (const char* env = std::getenv("HISPMV_COL_TILE_BYTES")) c->col_tile_bytes = std::atoll(env);
+    c->format_opts = FormatOptions::from_env();
     if (const char* env = std::getenv("HISPMV_CARRY"))
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     if (const char* env = std::getenv("HISPMV_BATCH_GRAPH")) c->batch_graphs = std::atoi(env) != 0;
@@ -807,10 +481,6 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
         if ((e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(join)");
     }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(fork)");
-    if (const char* env = std::getenv("HISPMV_FORMAT"))
-        c->format_mode = !std::strcmp(env, "slices") ? 0 : !std::strcmp(env, "tts") ? 1 : 2;
-    if (const char* env_b = std::getenv("HISPMV_BAND_TILES")) c->band_tiles = std::atoi(env_b) != 0;
-    if (const char* env_g = std::getenv("HISPMV_TTS_GEOMETRY")) c->tts_geometry = !std::strcmp(env_g, "standard") ? 0 : !std::strcmp(env_g, "tall") ? 1 : !std::strcmp(env_g, "paired") ? 3 : !std::strcmp(env_g, "zerofill") ? 4 : 2;
     if (const char* env = std::getenv("HISPMV_PREP"))
         c->prep_mode = !std::strcmp(env, "host") ? 0 : !std::strcmp(env, "device") ? 1 : 2;
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1719,6 +1389,34 @@ HISPMV_API int hispmv_prep_from_mtx(hispmv_prep** out, const char* path, int fla
 }
 
 HISPMV_API void hispmv_prep_free(hispmv_prep* p) { delete p; }
+
+// The format / tiling decision of the loader for this matrix on a device with n_cus compute units, host-only
+// (hispmv_choose.cpp: the same function hispmv_create_sparse_handle* calls).  Works on a copy of the prepared CSR.
+HISPMV_API int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_t out[16]) {
+    if (!p || !out || n_cus <= 0) return HISPMV_EINVAL;
+    try {
+        Csr copy = p->csr;
+        FormatOptions opt = FormatOptions::from_env();
+        opt.decide_only = true;
+        const FormatChoice ch = choose_format(std::move(copy), nullptr, n_cus, opt);
+        int64_t n_slices = 0, n_elems = 0, n_split = 0, global_elems = 0;
+        for (const HostPart& q : ch.parts) {
+            if (q.is_tts) { n_slices += (int64_t)q.tts.col_base.size(); n_elems += q.tts.nnz + q.tts.n_fillers; n_split += (int64_t)q.tts.fix.size() / 4; }
+            else { n_slices += q.st.n_slices; n_elems += q.st.n_elems; n_split += (int64_t)q.st.fix.size(); global_elems += q.plan.lds_floats > 0 ? q.plan.global_elems : q.st.n_slices * (int64_t)kSliceElems; }
+        }
+        const HostPart& p0 = ch.parts[0];
+        out[0] = ch.format; out[1] = ch.parts.size() > 1 ? (ch.tile_kind ? ch.tile_kind : 1) : 0; out[2] = (int64_t)ch.parts.size();
+        out[3] = ch.col_tile_width; out[4] = ch.col_tile_base; out[5] = ch.l2_tiles ? 1 : 0;
+        out[6] = ch.format == 1 ? p0.tts.geometry.threads : p0.plan.block_threads;
+        out[7] = ch.format == 1 ? p0.tts.geometry.max_slots / kTtsChunk : p0.plan.group_slices;
+        out[8] = ch.format == 1 ? 0 : p0.plan.lds_floats;
+        out[9] = n_slices; out[10] = n_elems; out[11] = n_split;
+        out[12] = (int64_t)(ch.tts_lines_per_gather * 1000.0 + 0.5);
+        out[13] = global_elems;        // elements that gather x through L2 (slice streams: outside their window, or no window at all)
+        out[14] = 0; out[15] = 0;
+        return HISPMV_OK;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
 
 HISPMV_API int hispmv_prep_dims(const hispmv_prep* p, int64_t d[8]) {
     if (!p || !d) return HISPMV_EINVAL;

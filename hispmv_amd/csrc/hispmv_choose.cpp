@@ -1,0 +1,345 @@
+// hispmv_choose.cpp -- see hispmv_choose.h.  Host-only.
+#include "hispmv_choose.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+
+namespace hispmv {
+
+FormatOptions FormatOptions::from_env() {
+    FormatOptions o;
+    if (const char* e = std::getenv("HISPMV_FORMAT")) o.format_mode = !std::strcmp(e, "slices") ? 0 : !std::strcmp(e, "tts") ? 1 : 2;
+    if (const char* e = std::getenv("HISPMV_BAND_TILES")) o.band_tiles = std::atoi(e) != 0;
+    if (const char* e = std::getenv("HISPMV_TTS_GEOMETRY"))
+        o.tts_geometry = !std::strcmp(e, "standard") ? 0 : !std::strcmp(e, "tall") ? 1 : !std::strcmp(e, "paired") ? 3 : !std::strcmp(e, "zerofill") ? 4 : 2;
+    if (const char* e = std::getenv("HISPMV_COL_TILE_BYTES")) o.col_tile_bytes = std::atoll(e);
+    if (const char* e = std::getenv("HISPMV_TTS_MIN_NNZ")) o.tts_min_nnz = std::atoll(e);
+    o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
+    return o;
+}
+
+namespace {
+
+// Column range [c0, c1) of a CSR matrix as its own CSR (global column ids are kept: x is shared).
+Csr column_tile(const Csr& m, int32_t c0, int32_t c1) {
+    Csr t;
+    t.rows = m.rows; t.cols = m.cols;
+    t.row_ptr.assign((size_t)m.rows + 1, 0);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        t.row_ptr[(size_t)i + 1] = std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0);
+    }
+    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
+    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
+        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
+        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
+        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
+    }
+    return t;
+}
+
+// Offsets [o0, o1) from the (scaled) diagonal of a CSR matrix as its own CSR: row i keeps its columns in
+// [i*cols/rows + o0, i*cols/rows + o1) (global column ids are kept: x is shared).  open_lo / open_hi: no lower / upper bound.
+Csr band_tile(const Csr& m, int64_t o0, int64_t o1, bool open_lo, bool open_hi) {
+    Csr t;
+    t.rows = m.rows; t.cols = m.cols;
+    t.row_ptr.assign((size_t)m.rows + 1, 0);
+    auto bounds = [&](int32_t i, int32_t& c0, int32_t& c1) {
+        const int64_t cen = (int64_t)i * m.cols / m.rows;
+        c0 = open_lo ? 0 : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o0));
+        c1 = open_hi ? m.cols : (int32_t)std::max<int64_t>(0, std::min<int64_t>(m.cols, cen + o1));
+    };
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        int32_t c0, c1; bounds(i, c0, c1);
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        t.row_ptr[(size_t)i + 1] = c1 > c0 ? std::lower_bound(b, e, c1) - std::lower_bound(b, e, c0) : 0;
+    }
+    for (int32_t i = 0; i < m.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
+    t.col.resize((size_t)t.row_ptr[m.rows]); t.val.resize((size_t)t.row_ptr[m.rows]);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int32_t i = 0; i < m.rows; ++i) {
+        int32_t c0, c1; bounds(i, c0, c1);
+        const int32_t* b = m.col.data() + m.row_ptr[i];
+        const int32_t* e = m.col.data() + m.row_ptr[(size_t)i + 1];
+        const int64_t k0 = m.row_ptr[i] + (std::lower_bound(b, e, c0) - b);
+        const int64_t n = t.row_ptr[(size_t)i + 1] - t.row_ptr[i];
+        std::copy_n(m.col.data() + k0, n, t.col.data() + t.row_ptr[i]);
+        std::copy_n(m.val.data() + k0, n, t.val.data() + t.row_ptr[i]);
+    }
+    return t;
+}
+
+// Width (in columns) of a column tile; 0 = no tiling.  Tiling applies only when the plan of the whole
+// matrix gathers x through L2 (no LDS window) and x exceeds `tile_bytes` (default 4 MiB = one XCD's
+// L2, i.e. tiles of 2-4 MiB; HISPMV_COL_TILE_BYTES overrides, 0 disables).
+int32_t column_tile_width(int32_t cols, int64_t tile_bytes) {
+    if (tile_bytes <= 0 || (int64_t)cols * 4 <= tile_bytes + tile_bytes / 2) return 0;
+    // 2, 4 or 8 tiles: in a batch call the tiles of a matrix run in the same round, each pinned to 8 / tiles of the
+    // 8 XCDs, so that an XCD's L2 holds one tile's part of x (more than 8 tiles' worth of x: 8 larger tiles)
+    int64_t tiles = ((int64_t)cols * 4 + tile_bytes - 1) / tile_bytes;
+    tiles = tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
+    const int64_t w = (((int64_t)cols + tiles - 1) / tiles + 63) & ~63LL;     // equal tiles, 256-byte aligned
+    return (int32_t)w;
+}
+
+// The launch plan of a part, then its device layout.  Two steps: a matrix that becomes a tile stream needs the plan (the
+// decision reads it) but not the device layout of the slice stream it drops (0.14 s on soc-Pokec's shape).
+void plan_part(HostPart& p, int n_cus) {
+    for (const FixEntry& f : p.st.fix) (f.len <= kFixShortMax ? p.fix_short : p.fix_long).push_back(f);
+    p.plan = make_plan(p.st, n_cus);     // also rewrites the column field of LDS-staged groups
+}
+void pack_part(HostPart& p, const FormatOptions& opt) {
+    if (opt.decide_only) return;
+    p.dstream = pack_device_stream(p.st, p.plan);
+    p.st.words = WordVec();   // the device layout replaces the host words
+}
+void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p, n_cus); pack_part(p, opt); }
+
+}  // namespace
+
+FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const FormatOptions& opt,
+                           const std::function<void(const char*)>& lap_fn) {
+    auto lap = [&](const char* what) { if (lap_fn) lap_fn(what); };
+    FormatChoice out;
+    out.parts.emplace_back();
+    out.parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
+    lap("slice stream (host) / adopt");
+    plan_part(out.parts[0], n_cus);            // (its device layout: once the format is decided, below)
+    lap("launch plan");
+    // Column tiling when the whole-matrix plan has to gather x through L2:
+    //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
+    //  * x larger than an XCD's L2: L2-sized tiles.
+    int32_t tw = 0, tbase = 0;
+    const LaunchPlan& whole = out.parts[0].plan;
+    // columns the matrix actually uses: a block of a larger matrix (a rank's shard: x is replicated at full length)
+    // is tiled over ITS column range, not over the width of x; the 0.1 % of elements at either end do not count
+    // (a shard also holds a few rows of the next block) -- they go to the first / last tile, which are open-ended
+    int32_t cmin = INT32_MAX, cmax = -1;
+    const int64_t nnz_all = csr.nnz();
+#pragma omp parallel for num_threads(host_threads()) reduction(min : cmin) reduction(max : cmax) schedule(static)
+    for (int64_t k = 0; k < nnz_all; ++k) { cmin = std::min(cmin, csr.col[(size_t)k]); cmax = std::max(cmax, csr.col[(size_t)k]); }
+    if (cmax >= cmin) {
+        // (bins of 2^shift columns, at most 1024 of them; every 4th entry of a large matrix: the cut is a 0.1 % quantile.
+        // A 64-bit division per entry made this pass 44 ms on soc-Pokec's shape.)
+        constexpr int kBins = 1024;
+        int shift = 0;
+        while ((((int64_t)cmax - cmin) >> shift) >= kBins) ++shift;
+        const int64_t bin_w = 1ll << shift;
+        const int64_t stride = nnz_all >= (4 << 20) ? 4 : 1;
+        std::vector<int64_t> hist(kBins, 0);
+#pragma omp parallel num_threads(host_threads())
+        {
+            std::vector<int64_t> local(kBins, 0);
+#pragma omp for schedule(static) nowait
+            for (int64_t k = 0; k < nnz_all; k += stride) local[(size_t)((uint32_t)(csr.col[(size_t)k] - cmin) >> shift)] += stride;
+#pragma omp critical
+            for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
+        }
+        const int64_t cut = nnz_all / 1000;
+        int lo = 0, hi = kBins - 1;
+        for (int64_t acc = 0; lo < hi && acc + hist[(size_t)lo] <= cut; ++lo) acc += hist[(size_t)lo];
+        for (int64_t acc = 0; hi > lo && acc + hist[(size_t)hi] <= cut; --hi) acc += hist[(size_t)hi];
+        const int64_t qlo = cmin + lo * bin_w, qhi = std::min<int64_t>(cmax, cmin + (hi + 1) * bin_w - 1);
+        cmin = (int32_t)qlo; cmax = (int32_t)qhi;
+    }
+    const int32_t used = cmax >= cmin ? cmax - (cmin & ~63) + 1 : 0;
+    // Scattered columns (no window pays): the transposed tile stream, when sorting a row tile's elements by column brings
+    // several of them onto each cache line of x (hispmv_tts.h).  Takes the place of the L2-sized column tiles below.
+    // (from 1 M entries: a tile is a long latency chain -- column-order pass, barrier, row-order pass per block --, the
+    // smallest matrices of the benchmark set run faster as slice streams: three alternating rounds, step of the set with
+    // two launch streams, threshold 64 K: 342-345 us, 1 M: 342-346 us, 4 M: 352-355 us; matrices alone: trans5 16.7 vs 10.1 us)
+    const int64_t tts_min = opt.tts_min_nnz;
+    // Candidates: plans without a window, and plans whose window leaves more than 5 % of the gathers to L2 (a wide band
+    // without column reuse between rows: the pessimistic stand-ins of PFlow_742 / Si41Ge41H72, 86 and 69 us with a 128 KiB
+    // window of the most used blocks) -- there the two formats are compared by their L2 requests per element.
+    const int64_t all_elems = out.parts[0].st.n_slices * (int64_t)kSliceElems;
+    const double slice_requests = whole.lds_floats == 0 ? 1.0
+                                 : ((double)whole.global_elems + (double)whole.staged_floats / kFragBlock) / (double)std::max<int64_t>(all_elems, 1);
+    // (x at most two windows wide is cut into two column tiles that each run from LDS: mouse_gene 56 us that way, 77 us as
+    // a tile stream)
+    const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && opt.col_tile_bytes > 0 && out.parts[0].st.n_slices >= 4096;
+    const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
+    // (x of at most 256 KiB stays in L1 / L2 whatever the order of the gathers: the slice stream's per-element gathers are cheap
+    // there and a tile is a longer latency chain -- the 1024 x 8192 layer of apps/model_test.py: 10.0 us as a slice stream
+    // against 15.0 us as a tile stream, 8 vectors through `linear` 33 against 58 us.  Not 1 MiB: Si41Ge41H72 as an
+    // unstructured band, 742 KB of x, is 39.5 us as a tile stream and 45 as a slice stream; the pessimistic family's step
+    // 0.329 -> 0.363 ms with that threshold.)
+    const bool x_is_small = (int64_t)used * 4 <= (256 << 10);
+    // BAND TILES: a banded matrix whose band is wider than an LDS window -- every group of rows touches band + rows columns --
+    // is cut along the DIAGONAL: part t holds the elements whose offset from the (scaled) diagonal lies in the t-th of P equal
+    // ranges of the band.  A group of a part then touches (band / P + its rows) columns: a window that fits, every element in
+    // it, 6-byte elements from LDS instead of per-element gathers through the cache -- the reference's column tiling
+    // (tileAndPad spmv-helper.cpp:242-263) in the coordinates of a band.  Part 0 writes y, the others partial vectors that
+    // the tail launch merges; all parts share one grid.  (PFlow_742 as an unstructured band +-20000: 82 us as a tile stream.)
+    if (candidate && opt.band_tiles && opt.format_mode != 1 && nnz_all >= (4 << 20) && csr.rows > 1 && !x_is_small) {
+        constexpr int kBins = 4096;
+        const int64_t span = (int64_t)csr.cols + csr.rows;            // offsets lie in (-cols, cols)
+        int shift = 0;
+        while ((2 * span >> shift) >= kBins) ++shift;
+        std::vector<int64_t> hist(kBins, 0);
+#pragma omp parallel num_threads(host_threads())
+        {
+            std::vector<int64_t> local(kBins, 0);
+#pragma omp for schedule(static) nowait
+            for (int32_t i = 0; i < csr.rows; ++i) {
+                const int64_t cen = (int64_t)i * csr.cols / csr.rows;
+                for (int64_t k = csr.row_ptr[i]; k < csr.row_ptr[(size_t)i + 1]; ++k) local[(size_t)((csr.col[(size_t)k] - cen + span) >> shift)]++;
+            }
+#pragma omp critical
+            for (int b = 0; b < kBins; ++b) hist[(size_t)b] += local[(size_t)b];
+        }
+        const int64_t cut = nnz_all / 1000;
+        int lo = 0, hi = kBins - 1;
+        for (int64_t acc = 0; lo < hi && acc + hist[(size_t)lo] <= cut; ++lo) acc += hist[(size_t)lo];
+        for (int64_t acc = 0; hi > lo && acc + hist[(size_t)hi] <= cut; --hi) acc += hist[(size_t)hi];
+        const int64_t dmin = ((int64_t)lo << shift) - span, dmax = (((int64_t)hi + 1) << shift) - span - 1;
+        const int64_t W = dmax - dmin + 1;
+        constexpr int64_t kTarget = 20 * 1024;                        // offsets per part: leaves ~12 K floats of window for the rows of a group
+        lap("band histogram");
+        if (W > kTarget && W <= 8 * kTarget && W < (int64_t)used) {
+            const int P = (int)((W + kTarget - 1) / kTarget);
+            const int64_t width = (((W + P - 1) / P) + 63) & ~63LL;
+            std::vector<HostPart> parts;
+            bool ok = true;
+            for (int t = 0; t < P && ok; ++t) {
+                Csr tile = band_tile(csr, dmin + t * width, dmin + (t + 1) * width, t == 0, t == P - 1);
+                parts.emplace_back();
+                parts.back().st = build_stream(tile);
+                finish_part(parts.back(), std::max(1, n_cus / P), opt);
+                const HostPart& q = parts.back();
+                ok = q.plan.lds_floats > 0 && q.plan.global_elems * 50 <= q.st.n_slices * (int64_t)kSliceElems;
+            }
+            lap("band tiles");
+            if (ok) {
+                out.parts = std::move(parts);
+                out.tile_kind = 2; out.col_tile_width = (int)width; out.col_tile_base = (int)dmin;
+                csr = Csr{};
+                return out;
+            }
+        }
+    }
+    if (candidate && opt.format_mode != 0 && ((nnz_all >= tts_min && !x_is_small) || (opt.format_mode == 1 && nnz_all >= 64 * 1024))) {
+        lap("column range / histogram");
+        TtsGeometry g0;
+        g0.zero_fill = opt.tts_geometry == 4;        // HISPMV_TTS_GEOMETRY=zerofill: the standard sizes, no filler words (experiment)
+        TtsStream ts = build_tts(csr, 0, g0);
+        lap("tile stream packer");
+        if (ts.lines_per_gather <= 8.0 && opt.tts_small) {
+            // experiment (off by default: measured slower): cheap gathers -> the half-LDS geometry, two workgroups per CU
+            TtsGeometry small;
+            small.max_slots = kTtsSmallSlots; small.max_rows = kTtsSmallRows; small.tiles_wanted = 512;
+            TtsStream t2 = build_tts(csr, 0, small);
+            if (t2.lines_per_gather <= 16.0) ts = std::move(t2);
+        }
+        // (a tile is one workgroup's work; the packer cuts rows longer than a tile and a quarter into pieces and orders
+        // the tiles longest first, so this only rejects what is left: tiles capped by their row count next to full ones)
+        const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
+        const bool fewer_requests = ts.lines_per_gather / 64.0 + 0.1 < slice_requests;     // (+0.1: the two passes and barriers of a block)
+        if (opt.format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced && fewer_requests)) {
+            // The TALL geometry (hispmv_tts.h): when a gather of the 8 K-row tiles still touches many lines of x and x is
+            // larger than an XCD's L2, the matrix becomes two column parts of 16 K-row tiles -- the same number of tiles
+            // and elements per tile over half the column range (soc-Pokec: 23 -> 13 lines per gather), and in a batch
+            // call each part is pinned to four XCDs whose L2s then hold its half of x.  HISPMV_TTS_GEOMETRY=standard|tall|paired|auto
+            // (standard is the default: the gathers are bound by the lines they pull through the cache, and the tall tiles
+            // pay for fewer lines with 46 % more row-order slots -- DESIGN.md 2.2).
+            std::vector<TtsStream> tall;
+            const bool paired = opt.tts_geometry == 3;
+            const bool want_tall = opt.tts_geometry == 1 || paired ||
+                                   (opt.tts_geometry == 2 && ts.lines_per_gather > 16.0 && (int64_t)used * 4 > (4 << 20) && csr.rows >= 64 * kTtsTallRows);
+            if (want_tall) {
+                const std::vector<int32_t> cuts = tts_column_cuts(csr, kTtsTallParts);
+                double lines = 0; int64_t slices = 0;
+                bool ok = true;
+                for (int q = 0; q < kTtsTallParts && ok; ++q) {
+                    Csr part = csr_column_range(csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? csr.cols : cuts[(size_t)q]);
+                    tall.push_back(build_tts(part, 0, paired ? tts_paired_geometry(n_cus) : tts_tall_geometry(n_cus, kTtsTallParts)));
+                    const TtsStream& t = tall.back();
+                    lines += t.lines_per_gather * (double)t.col_base.size(); slices += (int64_t)t.col_base.size();
+                    ok = t.max_tile_slots <= 2 * (t.total_slots / std::max<int64_t>(1, (int64_t)t.tiles.size())) + 4096;
+                }
+                // (auto: only when it pays -- at least a quarter fewer lines per gather)
+                if (!ok || (opt.tts_geometry == 2 && lines / (double)std::max<int64_t>(slices, 1) > 0.75 * ts.lines_per_gather)) tall.clear();
+            }
+            out.format = 1;
+            if (!tall.empty()) {
+                out.parts.clear();
+                double lines = 0; int64_t slices = 0;
+                for (TtsStream& t : tall) {
+                    out.parts.emplace_back();
+                    HostPart& p = out.parts.back();
+                    p.is_tts = true;
+                    lines += t.lines_per_gather * (double)t.col_base.size(); slices += (int64_t)t.col_base.size();
+                    p.tts = std::move(t);
+                }
+                out.tts_lines_per_gather = lines / (double)std::max<int64_t>(slices, 1);
+                out.tile_kind = 1;
+                out.col_tile_width = tts_column_cuts(csr, kTtsTallParts)[0];
+            } else {
+                HostPart& p = out.parts[0];
+                p.is_tts = true;
+                p.tts = std::move(ts);
+                p.st = SliceStream{}; p.dstream = DeviceStream{}; p.fix_short = {}; p.fix_long = {};
+                out.tts_lines_per_gather = p.tts.lines_per_gather;
+            }
+            csr = Csr{};
+            return out;
+        }
+    }
+    // (a window that leaves more than a tenth of the gathers to L2 counts as "does not fit" here)
+    const bool spilling = whole.lds_floats > 0 && whole.global_elems * 10 > out.parts[0].st.n_slices * (int64_t)kSliceElems;
+    if (used > 0 && (whole.lds_floats == 0 || spilling)) {
+        if (used <= 2 * kMaxLdsFloats && opt.col_tile_bytes > 0 && out.parts[0].st.n_slices >= 4096)
+            tw = ((used + 1) / 2 + 63) & ~63;
+        else if (whole.lds_floats == 0) tw = column_tile_width(used, opt.col_tile_bytes);
+        tbase = cmin & ~63;
+    }
+    if (tw > 0) {
+        out.col_tile_width = tw; out.col_tile_base = tbase; out.tile_kind = 1;
+        out.parts.clear();
+        for (int64_t c0 = tbase; c0 <= cmax; c0 += tw) {
+            const bool first = c0 == tbase, last = c0 + tw > cmax;           // the end tiles are open-ended
+            Csr tile = column_tile(csr, first ? 0 : (int32_t)c0, last ? csr.cols : (int32_t)(c0 + tw));
+            out.parts.emplace_back();
+            out.parts.back().st = build_stream(tile);
+            // the tiles of a matrix run in one grid: a two-window tile (resident plan: one long chunk per workgroup, its x
+            // window staged once) is planned for its share of the CUs
+            const int n_tiles = (int)((cmax - tbase) / tw + 1);
+            finish_part(out.parts.back(), used <= 2 * kMaxLdsFloats ? std::max(1, n_cus / std::max(1, n_tiles)) : n_cus, opt);
+        }
+        // two tiles were meant to bring the x window into LDS: if they still gather through L2, tiling only
+        // costs a launch and a read-modify-write of y -- go back to the single stream
+        bool lds_goal = used <= 2 * kMaxLdsFloats, all_lds = true;
+        for (auto& p : out.parts)
+            all_lds = all_lds && p.plan.lds_floats > 0 && p.plan.global_elems * 50 <= p.st.n_slices * (int64_t)kSliceElems;
+        if ((lds_goal && !all_lds) || out.parts.size() < 2) {
+            out.parts.clear();
+            out.col_tile_width = 0; out.col_tile_base = 0; out.tile_kind = 0;
+            out.parts.emplace_back();
+            out.parts[0].st = build_stream(csr);
+            finish_part(out.parts[0], n_cus, opt);
+        } else if (!lds_goal) {
+            const size_t np = out.parts.size();
+            bool same = np == 2 || np == 4 || np == 8;
+            for (auto& p : out.parts) same = same && p.plan.block_threads == out.parts[0].plan.block_threads && p.plan.lds_floats == 0;
+            out.l2_tiles = same;
+        }
+    }
+    csr = Csr{};
+    lap("column tiles (if any)");
+    if (tw == 0) pack_part(out.parts[0], opt);       // the whole-matrix stream stays: its device layout now
+    lap("device layout");
+    return out;
+}
+
+}  // namespace hispmv

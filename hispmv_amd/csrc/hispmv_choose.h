@@ -1,0 +1,54 @@
+// hispmv_choose.h -- per-matrix FORMAT AND TILING CHOICE: slice stream or transposed tile stream, column tiles, band tiles.
+// The MI355X analogue of the reference's per-matrix configuration search (automation_tool/src/dse.py:23-95 picks the
+// hardware configuration per matrix from its row statistics; tileAndPad spmv-helper.cpp:242-263 decides the tiling).
+// Host-only code (no HIP): the loader (hispmv_abi.cpp) calls choose_format() for every sparse handle, the host-only entry
+// hispmv_prep_choose_format() exposes the same decision to tests on a CPU-only box, tools/sanitize_host.sh runs it under
+// ASan/UBSan.  Until round 3 this logic lived inside hispmv_abi.cpp (compiled by hipcc, reachable only with a device).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+#include "hispmv_plan.h"
+#include "hispmv_prep.h"
+#include "hispmv_tts.h"
+
+namespace hispmv {
+
+// The host side of one part of a sparse matrix: a slice stream with its launch plan and device layout, or a tile stream.
+struct HostPart {
+    SliceStream st;
+    std::vector<FixEntry> fix_short, fix_long;   // rows cut by slice boundaries: chains of <= / > kFixShortMax slices
+    LaunchPlan plan;
+    DeviceStream dstream;                        // the planned stream in its device layout (compact / wide groups)
+    bool is_tts = false;
+    TtsStream tts;
+};
+
+struct FormatOptions {
+    int format_mode = 2;          // HISPMV_FORMAT: 0 slices always, 1 tile stream whenever the plan has no window, 2 auto
+    int tts_geometry = 0;         // HISPMV_TTS_GEOMETRY: 0 standard, 1 tall, 2 auto, 3 paired, 4 zerofill
+    bool band_tiles = true;       // HISPMV_BAND_TILES
+    int64_t col_tile_bytes = 4 << 20;   // HISPMV_COL_TILE_BYTES: x bytes per L2-sized column tile (0 = no tiling)
+    int64_t tts_min_nnz = 1 << 20;      // HISPMV_TTS_MIN_NNZ
+    bool tts_small = false;             // HISPMV_TTS_SMALL (experiment)
+    bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
+    static FormatOptions from_env();
+};
+
+struct FormatChoice {
+    int format = 0;               // 0 slice stream(s), 1 transposed tile stream(s)
+    int tile_kind = 0;            // parts.size() > 1: 1 column ranges, 2 ranges of the offset from the scaled diagonal (band tiles)
+    int col_tile_width = 0, col_tile_base = 0;
+    bool l2_tiles = false;        // the column tiles gather x through L2: pinned to XCD subsets in a batch call
+    double tts_lines_per_gather = 0;
+    std::vector<HostPart> parts;
+};
+
+// Decides the device format of `csr` for a device with n_cus compute units and builds its parts.  `prebuilt` (may be NULL):
+// the whole-matrix slice stream when the device preprocessor has already made it.  `lap` (may be empty) is called with the
+// name of every finished phase (HISPMV_PREP_TRACE).  csr is consumed.
+FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const FormatOptions& opt,
+                           const std::function<void(const char*)>& lap = {});
+
+}  // namespace hispmv

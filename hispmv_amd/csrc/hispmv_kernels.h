@@ -107,7 +107,6 @@ struct MultiPrefix {
     uint8_t tiles[kMultiMax];
 };
 
-constexpr int kFixShortMax = 32;
 constexpr int kMaxBatch = 4;                // vectors one pass of the batched slice kernel takes (carry holds kMaxBatch * n_slices)
 
 // Once per process/device before the first launch (raises the dynamic-LDS limit of the slice kernels).

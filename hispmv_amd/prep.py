@@ -130,3 +130,27 @@ def prep_from_mtx(path, flavor: int = 0) -> Prepared:
     if rc != HISPMV_OK:
         raise OSError(lib.hispmv_prep_last_error().decode())
     return _collect(p)
+
+
+FORMAT_FIELDS = ("format", "tile_kind", "parts", "tile_width", "tile_base", "l2_tiles", "threads", "group", "lds_floats", "n_slices",
+                 "n_elems", "n_split", "lines_per_gather_x1000", "l2_gather_elems")
+
+
+def choose_format_from_csr(row_ptr, col_idx, values, rows: int, cols: int, n_cus: int = 256) -> dict:
+    """The loader's format / tiling decision for a CSR matrix on an `n_cus`-CU device (hispmv_prep_choose_format): host-only,
+    the same code path hispmv_create_sparse_handle_from_csr takes.  The CSR goes in as COO triplets in row-major order."""
+    rp = np.asarray(row_ptr, dtype=np.int64)
+    r = np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp).astype(np.int64))
+    c = np.ascontiguousarray(col_idx, dtype=np.int32)
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    p = C.c_void_p()
+    rc = lib.hispmv_prep_from_coo(C.byref(p), C.c_void_p(r.ctypes.data), C.c_void_p(c.ctypes.data), C.c_void_p(v.ctypes.data), r.size, rows, cols)
+    if rc != HISPMV_OK:
+        raise ValueError(lib.hispmv_prep_last_error().decode())
+    try:
+        out = (C.c_int64 * 16)()
+        if lib.hispmv_prep_choose_format(p, int(n_cus), out) != HISPMV_OK:
+            raise ValueError(lib.hispmv_prep_last_error().decode())
+        return dict(zip(FORMAT_FIELDS, (int(x) for x in out)))
+    finally:
+        lib.hispmv_prep_free(p)

@@ -206,6 +206,16 @@ const int32_t* hispmv_prep_fix(const hispmv_prep* p);         /* n_split_rows x 
  * floats per wavefront, workgroups, total dynamic LDS bytes per workgroup. */
 int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
 
+/* The FORMAT AND TILING the loader would choose for this matrix on a device with n_cus compute units -- the MI355X analogue of
+ * the reference's per-matrix configuration search (automation_tool/src/dse.py:23-95) -- computed by the same host-only function
+ * hispmv_create_sparse_handle* calls (hispmv_amd/csrc/hispmv_choose.cpp; no device needed).  out[0..13] = format (0 slice
+ * stream, 1 transposed tile stream), tile kind (0 untiled, 1 column tiles, 2 band tiles), parts, tile width, tile base, 1 if the
+ * tiles gather x through L2 (XCD-pinned in a batch call), workgroup threads / slices per workgroup (tile stream: K-slots per
+ * block) / LDS window floats of part 0, slices, stream elements, rows cut between slices (pieces), 1000 x lines per gather of a
+ * tile stream, elements that gather x through L2.  Honours the HISPMV_FORMAT / _BAND_TILES / _TTS_GEOMETRY / _COL_TILE_BYTES /
+ * _TTS_MIN_NNZ switches like the loader. */
+int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_t out[16]);
+
 /* Applies that plan to the prepared stream IN PLACE (the words of LDS-staged groups then carry window
  * indices instead of columns -- or 0x40000000 | column for the elements of the group whose 64-byte block of x
  * is not in the window) and exposes its tables: groups = n x {frag_begin, frag_count, lds_floats, elements

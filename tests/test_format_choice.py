@@ -1,0 +1,94 @@
+"""The loader's FORMAT AND TILING DECISION as host code under test: hispmv_amd/csrc/hispmv_choose.cpp through
+the host-only entry hispmv_prep_choose_format -- the MI355X analogue of the reference's per-matrix configuration search
+(/root/reference/automation_tool/src/dse.py:23-95).  No device needed.
+
+* today's choices for every matrix the benchmark and the parity tests run -- the 20 shapes of the SuiteSparse set in both
+  stand-in families, C3, the sparse C4 layers -- are pinned in tests/golden/format_choices.json
+  (tests/golden/make_format_choices.py regenerates it, on purpose, when the planner changes);
+* the decision's branches on small matrices built for them, with the environment switches the loader honours."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = json.loads((ROOT / "tests" / "golden" / "format_choices.json").read_text())
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+
+
+def test_pinned_choices_for_every_benchmarked_matrix():
+    import make_format_choices as G
+    seen = set()
+    bad = []
+    for name, rows, cols, rp, ci, va in G.cases():
+        got = G.decide(rows, cols, rp, ci, va)
+        seen.add(name)
+        if got != GOLD[name]:
+            bad.append((name, {k: (GOLD[name][k], got[k]) for k in got if got[k] != GOLD[name][k]}))
+    assert not bad, f"format choice changed (golden, now): {bad}"
+    assert seen == set(GOLD), sorted(set(GOLD) ^ seen)
+    # what the pins say, in words (the plans that carry the headline number)
+    s = {k.split(":", 1)[1]: v for k, v in GOLD.items() if k.startswith("structured:")}
+    assert [n for n, v in s.items() if v["format"] == 1] == ["soc-Pokec", "nxp1", "analytics", "boyd2", "language"]
+    assert s["mouse_gene"]["tile_kind"] == 1 and s["mouse_gene"]["parts"] == 2 and s["mouse_gene"]["lds_floats"] > 0      # two LDS-window column tiles
+    assert GOLD["uniform:PFlow_742"]["tile_kind"] == 2 and GOLD["uniform:Si41Ge41H72"]["tile_kind"] == 2                  # band tiles
+    assert all(v["threads"] == 256 for n, v in s.items() if v["n_elems"] < (3 << 20) and v["format"] == 0)
+
+
+def _band(rows, per_row, half, seed=3):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+    c = np.clip(r + rng.integers(-half, half + 1, size=r.size), 0, rows - 1)
+    order = np.lexsort((c, r))
+    rp = np.arange(rows + 1, dtype=np.int64) * per_row
+    return rp, c[order].astype(np.int32), np.ones(r.size, np.float32)
+
+
+def _choose_in_child(env_extra, expr):
+    """The switches are read from the environment at decision time; a child process keeps this one's environment clean."""
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_format_choice import _band\n"
+            "from hispmv_amd.prep import choose_format_from_csr\n"
+            "rp, ci, va = %s\n"
+            "print(json.dumps(choose_format_from_csr(rp, ci, va, len(rp) - 1, len(rp) - 1, 256)))\n") % (str(ROOT), str(ROOT / "tests"), expr)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=300)
+    assert p.returncode == 0, p.stderr[-800:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_branches_and_switches():
+    from hispmv_amd.prep import choose_format_from_csr
+    # a narrow band: one slice stream with an LDS window, nothing gathers through L2
+    rp, ci, va = _band(200000, 12, 400)
+    d = choose_format_from_csr(rp, ci, va, 200000, 200000, 256)
+    assert (d["format"], d["tile_kind"], d["parts"]) == (0, 0, 1) and d["lds_floats"] > 0 and d["l2_gather_elems"] == 0
+    # a wide unstructured band of 5 M entries: cut along the diagonal (band tiles), every part with a clean window
+    wide = "_band(250000, 20, 30000)"
+    d = _choose_in_child({}, wide)
+    assert d["format"] == 0 and d["tile_kind"] == 2 and d["parts"] >= 2 and d["lds_floats"] > 0 and d["tile_base"] < 0
+    # ... the same matrix without band tiles: the tile stream (its gathers share cache lines); without either: slices through L2
+    d = _choose_in_child({"HISPMV_BAND_TILES": "0"}, wide)
+    assert d["format"] == 1 and d["parts"] == 1 and 0 < d["lines_per_gather_x1000"] <= 32000
+    d = _choose_in_child({"HISPMV_BAND_TILES": "0", "HISPMV_FORMAT": "slices"}, wide)
+    assert d["format"] == 0 and d["tile_kind"] in (0, 1)
+    # below 1 M entries a scattered matrix stays a slice stream of 256-thread groups that gather through L2 ...
+    small = "_band(100000, 8, 45000)"
+    d = _choose_in_child({}, small)
+    assert (d["format"], d["threads"], d["lds_floats"]) == (0, 256, 0) and d["l2_gather_elems"] == d["n_slices"] * 1024
+    # ... unless the threshold is lowered (HISPMV_TTS_MIN_NNZ) or the tile stream is forced
+    assert _choose_in_child({"HISPMV_TTS_MIN_NNZ": "100000"}, small)["format"] == 1
+    assert _choose_in_child({"HISPMV_FORMAT": "tts"}, small)["format"] == 1
+    # the tall geometry of a tile stream: two column parts
+    d = _choose_in_child({"HISPMV_BAND_TILES": "0", "HISPMV_TTS_GEOMETRY": "tall"}, wide)
+    assert d["format"] == 1 and d["parts"] == 2 and d["tile_kind"] == 1 and d["tile_width"] > 0
+    # fewer compute units, another plan: the decision is a function of (matrix, n_cus) only
+    rp, ci, va = _band(200000, 12, 400)
+    a = choose_format_from_csr(rp, ci, va, 200000, 200000, 256)
+    b = choose_format_from_csr(rp, ci, va, 200000, 200000, 256)
+    assert a == b
+    assert choose_format_from_csr(rp, ci, va, 200000, 200000, 8)["format"] == 0

@@ -1,9 +1,11 @@
 // Sanitizer driver for the host side (tools/sanitize_host.sh): random matrices of five kinds through
-// coo_to_csr -> build_stream -> make_plan -> device layout, the transposed tile stream, unsorted CSR rows, and the
+// coo_to_csr -> build_stream -> make_plan -> device layout, the transposed tile stream, the format / tiling choice
+// (choose_format with its band-tile, column-tile and tile-stream branches forced by thresholds), unsorted CSR rows, and the
 // MatrixMarket reader on the files given as arguments.
 #include <cstdio>
 #include <random>
 
+#include "hispmv_choose.h"
 #include "hispmv_plan.h"
 #include "hispmv_prep.h"
 #include "hispmv_tts.h"
@@ -34,6 +36,13 @@ int main(int argc, char** argv) {
         for (int cus : {256, 8, 1}) { SliceStream copy = st; LaunchPlan p = make_plan(copy, cus); DeviceStream d = pack_device_stream(copy, p); (void)d; }
         TtsStream ts = build_tts(m, t % 3 == 0 ? 5000 : 0);                      // the second device format
         (void)ts;
+        {   // the loader's decision, every branch reachable at this size: tile streams from 1 K entries, tiny column tiles, each geometry
+            FormatOptions o;
+            o.tts_min_nnz = 1024; o.col_tile_bytes = (t % 2) ? 4096 : (4 << 20); o.format_mode = t % 4 == 3 ? 1 : 2; o.tts_geometry = t % 5; o.decide_only = t % 3 == 0;
+            Csr copy = m;
+            FormatChoice ch = choose_format(std::move(copy), nullptr, t % 2 ? 256 : 8, o);
+            if (ch.parts.empty()) { std::puts("choose_format: no parts"); return 1; }
+        }
         if (t % 7 == 0) {                                                        // CSR handed over with unsorted rows
             Csr u = m;
             for (int32_t i = 0; i + 1 <= u.rows; ++i) {
@@ -54,6 +63,15 @@ int main(int argc, char** argv) {
         Csr m = coo_to_csr(rows, rows, (long)r.size(), r.data(), c.data(), v.data());
         SliceStream st = build_stream(m);
         LaunchPlan p = make_plan(st, 256);
+        {   // ... and a wide unstructured band of 5 M entries: the band-tile branch
+            const int br = 250000, bper = 20, half = 30000;
+            std::vector<int32_t> r2, c2; std::vector<float> v2;
+            std::mt19937 g2(9);
+            for (int i = 0; i < br; ++i) for (int k = 0; k < bper; ++k) { r2.push_back(i); c2.push_back((int)std::min<long>(br - 1, std::max<long>(0, (long)i - half + (long)(g2() % (2 * half))))); v2.push_back(1.f); }
+            Csr mb = coo_to_csr(br, br, (long)r2.size(), r2.data(), c2.data(), v2.data());
+            FormatChoice ch = choose_format(std::move(mb), nullptr, 256, FormatOptions());
+            std::printf("wide band: format %d, tile kind %d, %zu parts\n", ch.format, ch.tile_kind, ch.parts.size());
+        }
         std::printf("stencil: slices %lld, %d threads, %d slices per workgroup, window %d floats\n", (long long)st.n_slices, p.block_threads, p.group_slices, p.lds_floats);
     }
     std::puts("sanitize_host: done");

@@ -67,24 +67,35 @@ __global__ __launch_bounds__(kAllThreads) void xsweep_kernel(const Tile* __restr
         // ---------------- producer
         const int pt = threadIdx.x - kWaves * 64;            // 0 .. kProducers*64-1
         constexpr int kQ = W / (kProducers * 64 * 4);        // float4 per thread and window
-        float4 nxt[kQ];
-        auto load_win = [&](int k) {
+#ifndef PREFETCH
+#define PREFETCH 3
+#endif
+        constexpr int PD = PREFETCH;                             // windows in flight (registers) ahead of the one being written
+        float4 r[PD][kQ];
+        auto load_win = [&](int k, float4* nxt) {
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 const long long c = (long long)T.col0 + (long long)k * W + q * (kProducers * 256) + pt * 4;
                 nxt[q] = (k < n_steps && c < cols) ? *(const float4*)(x + c) : float4{0, 0, 0, 0};
             }
         };
-        auto store_win = [&](int k) {
+        auto store_win = [&](int k, const float4* nxt) {
             float* b = win + (k % 3) * W;
 #pragma unroll
             for (int q = 0; q < kQ; ++q) *(float4*)(b + q * (kProducers * 256) + pt * 4) = nxt[q];
         };
-        load_win(0); store_win(0); load_win(1);
-        for (int k = 0; k < n_steps; ++k) {
-            store_win(k + 1);
-            load_win(k + 2);
-            __syncthreads();
+        load_win(0, r[0]); store_win(0, r[0]);
+#pragma unroll
+        for (int j = 0; j < PD; ++j) load_win(j + 1, r[j]);      // r[j] holds window j + 1
+        for (int k = 0; k < n_steps; k += PD) {
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                if (k + j < n_steps) {
+                    store_win(k + j + 1, r[j]);                  // requested PD steps ago
+                    load_win(k + j + 1 + PD, r[j]);
+                    __syncthreads();
+                }
+            }
         }
     } else {
         // ---------------- consumer
@@ -93,27 +104,32 @@ __global__ __launch_bounds__(kAllThreads) void xsweep_kernel(const Tile* __restr
         __syncthreads();                                      // B_0: counts, accumulators, windows 0 and 1 are in the LDS
         for (int k = 0; k < n_steps; ++k) total += cnt[k * kWaves + wave];
         total = __builtin_amdgcn_readfirstlane(total);
+        // The stream ring: D instructions in flight per wavefront, loads issued with inline asm and awaited with an explicit
+        // s_waitcnt vmcnt(D-1): hipcc's own wait insertion drains the queue once per trip of a loop like this one (vmcnt(1)
+        // before the oldest buffer), which exposes an HBM latency every D instructions -- and with one barrier per step the
+        // whole workgroup then runs at the pace of whichever wavefront is draining.
         constexpr int D = 8;
-        uint2 buf[D];
+        unsigned long long buf[D];
+        auto issue = [&](unsigned long long& dst, const uint2* ptr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
 #pragma unroll
-        for (int u = 0; u < D; ++u) buf[u] = sp[(size_t)u * 64];           // (the stream has D instructions of slack behind its end)
+        for (int u = 0; u < D; ++u) issue(buf[u], sp + (size_t)u * 64);           // (the stream has D instructions of slack behind its end)
         int k = 0, remaining = __builtin_amdgcn_readfirstlane((int)cnt[wave]);
         for (int pos = 0; pos < total; pos += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                {
-                    while (remaining == 0) { ++k; __syncthreads(); remaining = __builtin_amdgcn_readfirstlane((int)cnt[k * kWaves + wave]); }
-                    const uint2 e = buf[u];
-                    const float xv = win[e.y & 0xffffu];
-                    const unsigned slot = e.y >> 16;
-                    const float p = __builtin_bit_cast(float, e.x) * xv;
-                    const float a = acc[slot];
-                    acc[slot] = a + p;
-                    --remaining;
-                }
-                buf[u] = sp[(size_t)(pos + u + D) * 64];
+                if (remaining == 0) { ++k; __syncthreads(); remaining = __builtin_amdgcn_readfirstlane((int)cnt[k * kWaves + wave]); }
+                asm volatile("s_waitcnt vmcnt(7)" : "+v"(buf[u]) :: "memory");
+                const unsigned ev = (unsigned)buf[u], em = (unsigned)(buf[u] >> 32);
+                const float xv = win[em & 0xffffu];
+                const unsigned slot = em >> 16;
+                const float p = __builtin_bit_cast(float, ev) * xv;
+                const float a = acc[slot];
+                acc[slot] = a + p;
+                --remaining;
+                issue(buf[u], sp + (size_t)(pos + u + D) * 64);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]) :: "memory");
         while (k < n_steps - 1) { ++k; __syncthreads(); }   // every wavefront passes the same number of barriers
     }
     __syncthreads();
@@ -174,20 +190,25 @@ int main(int argc, char** argv) {
     std::vector<Tile> tiles;
     const int n_cus = 256;
     const int row_tiles_wanted = std::max(1, n_cus / parts);
-    {
-        const int64_t per_tile = (nnz + row_tiles_wanted - 1) / row_tiles_wanted;
+    {   // exactly row_tiles_wanted row ranges of ~equal elements; tile b runs on XCD b % 8 (workgroups are dealt round-robin over the
+        // XCDs): the tiles of a column part go to the same 8 / parts XCDs, so that the 32 CUs of an XCD sweep the SAME part of x at
+        // about the same pace and its L2 serves the windows (x is larger than one L2)
+        std::vector<int> cut((size_t)row_tiles_wanted + 1, 0);
         int r = 0;
-        while (r < rows) {
-            int64_t el = 0; int slots = 0; int r1 = r;
-            while (r1 < rows) {
-                const int64_t len = rp[(size_t)r1 + 1] - rp[r1];
-                const int s = (int)std::max<int64_t>(1, (len + (int64_t)parts * kPiece - 1) / ((int64_t)parts * kPiece)) + (len > (int64_t)parts * kPiece ? 1 : 0);     // bound per part
-                if (r1 > r && (el + len > per_tile || slots + s > tile_slots)) break;
-                el += len; slots += s; ++r1;
-            }
-            for (int p = 0; p < parts; ++p) { Tile t{}; t.row0 = r; t.n_rows = r1 - r; t.col0 = p * part_w; t.part = p; tiles.push_back(t); }
-            r = r1;
+        for (int i = 1; i <= row_tiles_wanted; ++i) {
+            const int64_t target = nnz * i / row_tiles_wanted;
+            while (r < rows && rp[(size_t)r + 1] <= target) ++r;
+            if (i == row_tiles_wanted) r = rows;
+            cut[i] = std::max(r, cut[i - 1]);
         }
+        const int per = 8 / parts > 0 ? 8 / parts : 1;
+        for (int b = 0; b < row_tiles_wanted * parts; ++b) {
+            const int xcd = b % 8, p = parts >= 8 ? xcd : xcd / per;
+            const int range = parts >= 8 ? b / 8 : (b / 8) * per + xcd % per;
+            Tile t{}; t.row0 = cut[range]; t.n_rows = cut[range + 1] - cut[range]; t.col0 = p * part_w; t.part = p;
+            tiles.push_back(t);
+        }
+        (void)tile_slots;
     }
     const int n_tiles = (int)tiles.size();
     printf("%d tiles (%d row ranges)\n", n_tiles, n_tiles / parts);
@@ -269,6 +290,7 @@ int main(int argc, char** argv) {
                     ins.push_back(std::move(I)); rest.swap(left);
                 }
                 O = rest;
+                if (ins.empty()) ins.emplace_back();     // every wavefront has >= 1 instruction in every step: the consumer passes ONE barrier per step change
                 for (auto& I : ins) emit(I, k);
                 P.elems += 0;
             }
@@ -301,7 +323,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n_tiles; ++i) order[i] = i;
     std::vector<int64_t> work((size_t)n_tiles);
     for (int t = 0; t < n_tiles; ++t) { work[t] = 0; for (int w = 0; w < kWaves; ++w) work[t] = std::max<int64_t>(work[t], (int64_t)packed[t].instr[w].size()); }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
+    // (256 tiles on 256 CUs: all resident at once; the order IS the XCD mapping)
     std::vector<Tile> sorted;
     for (int i : order) sorted.push_back(tiles[i]);
 
@@ -315,11 +337,15 @@ int main(int argc, char** argv) {
     auto launch = [&]() {
         if (W == 4096) hipLaunchKernelGGL(xsweep_kernel<4096>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
         else if (W == 8192) hipLaunchKernelGGL(xsweep_kernel<8192>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
+        else if (W == 3072) hipLaunchKernelGGL(xsweep_kernel<3072>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
+        else if (W == 6144) hipLaunchKernelGGL(xsweep_kernel<6144>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
         else if (W == 12288) hipLaunchKernelGGL(xsweep_kernel<12288>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
         else { printf("unsupported W\n"); exit(1); }
     };
     CK(hipFuncSetAttribute((const void*)xsweep_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     CK(hipFuncSetAttribute((const void*)xsweep_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    CK(hipFuncSetAttribute((const void*)xsweep_kernel<3072>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    CK(hipFuncSetAttribute((const void*)xsweep_kernel<6144>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     CK(hipFuncSetAttribute((const void*)xsweep_kernel<12288>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     launch(); CK(hipDeviceSynchronize());
     // --- check
