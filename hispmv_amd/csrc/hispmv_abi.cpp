@@ -3,174 +3,18 @@
 // FpgaHandle (pyhispmv/src/fpga_handle.cpp:40-388), which owns the XRT device, the
 // per-channel matrix arena and the kernel run object.  Host-side HIP runtime calls only;
 // the kernels live in hispmv_kernels.hip, the preprocessor in hispmv_prep.cpp.
-#include "../../include/hispmv.h"
-
-#include <hip/hip_runtime_api.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <mutex>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "hispmv_choose.h"
-#include "hispmv_kernels.h"
-#include "hispmv_plan.h"
-#include "hispmv_prep.h"
-#include "hispmv_prep_device.h"
-#include "hispmv_tts.h"
-
-#define HISPMV_API extern "C" __attribute__((visibility("default")))
+#include "hispmv_ctx.h"
 
 using namespace hispmv;
-
-namespace {
-
-struct Matrix {
-    bool dense = false;
-    int32_t rows = 0, cols = 0;
-    int64_t nnz = 0;
-    double prep_seconds = 0;
-    int64_t device_bytes = 0;
-    bool loaded = false;
-    // A sparse matrix is one slice stream, or -- when x is too large for an XCD's L2 and the columns
-    // are scattered -- one stream per COLUMN TILE (the reference's column tiling, tileAndPad
-    // spmv-helper.cpp:242-263, with L2 in the role of the BRAM x window): part 0 computes
-    // y = alpha*A0*x + beta*bias, part t > 0 accumulates y = alpha*At*x + 1*y.
-    struct Part : HostPart {                       // host side (hispmv_choose.h; released after upload) + device side
-        TtsDeviceMatrix tdev;                      //   of a tile stream
-        SpmvDeviceMatrix dev;                      //   of a slice stream
-    };
-    std::vector<Part> parts;
-    std::vector<float> dense_host;
-    int64_t n_slices = 0, n_elems = 0, n_split = 0, compact_slices = 0;
-    int plan_threads = 0, plan_group = 0, plan_lds = 0, col_tile_width = 0, col_tile_base = 0;
-    int tile_kind = 0;          // parts.size() > 1: 1 column ranges, 2 ranges of the offset from the (scaled) diagonal (band tiles)
-    int format = 0;             // 0 slice stream, 1 transposed tile stream
-    int index = -1;             // position in the context's handle list
-    double tts_lines_per_gather = 0;
-    bool l2_tiles = false;      // the column tiles gather x through L2 (L2-sized tiles): pinned to XCD subsets in a batch call
-    float* d_dense = nullptr;
-    // column tiles t > 0 write alpha*A_t*x here (tile t, vector v of a batched pass: d_ypart + ((t-1)*kMaxBatch + v)*rows);
-    // a merge pass adds them to y after the cut rows of every tile are fixed up
-    float* d_ypart = nullptr;
-    // column parts: for every part the fix-list index of each row (or -1), parts x rows, so that the merge of the partial
-    // vectors can apply the fix-ups of its rows itself (spmv_tail_multi_kernel); nullptr when a part has a long chain
-    int32_t* d_fix_of_row = nullptr;
-    std::vector<void*> allocs;
-};
-
-}  // namespace
-
-struct hispmv_ctx {
-    int device = 0;
-    int num_ch_A = 0, num_ch_B = 0, num_ch_C = 0, urams_per_pe = 0, fp_acc_latency = 0;
-    bool dense_overlay = false, pre_accumulator = false, row_dist_net = false;
-    hipStream_t stream = nullptr;
-    hipStream_t user_stream = nullptr;   // last caller-supplied stream a launch went to (hispmv_synchronize waits for it too)
-    // hispmv_spmv_device_batch: the independent main launches of a call (tile streams, slice classes) go to the caller's
-    // stream and to these side streams, forked from / joined to it with events, so that the tail of one grid overlaps the
-    // head of the next (HISPMV_BATCH_STREAMS=1 keeps everything on one stream)
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-    int batch_streams = 2;
-    int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first
-    bool batch_lanes_heavy_first = true;   // HISPMV_BATCH_LANES=rr: plain round-robin lanes
-    bool batch_graphs = true;    // HISPMV_BATCH_GRAPH=0: no HIP graph replay of batch calls
-    // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
-    // the three model_test layers: 49.9 us on one stream, 63.1 on two; the 20-matrix set: 353 -> 344 us with two)
-    int64_t batch_streams_min_bytes = 256ll << 20;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms = -1.0f;
-    std::mutex mu;
-    std::string err;
-    std::vector<std::unique_ptr<Matrix>> mats;
-    int selected = -1;
-    int64_t arena_budget = 0, arena_used = 0;
-    float *d_x = nullptr, *d_y = nullptr;     // device vectors of run_kernel / linear: [x | bias] and y
-    int64_t cap_x = 0, cap_y = 0;
-    int* h_err = nullptr;        // pinned, device-mapped word set by a kernel whose bounded carry wait expired
-    int* d_err = nullptr;        //   (its device address): read on the host after a stream sync, no copy
-    // run_kernel / linear with host vectors: x and bias are gathered in one pinned block and go up in ONE copy, y comes
-    // back through pinned memory too (pageable hipMemcpyAsync stages and synchronises per call: 3 copies + the error word
-    // cost ~65 us around a 20 us kernel)
-    float* h_stage = nullptr;
-    int64_t cap_stage = 0;
-    // hispmv_spmv_device_batch: the launches of one call signature (handles, vectors, beta == 0 or not) with their device
-    // tables, built on the first call and replayed afterwards
-    struct BatchLaunch {
-        int kind = 0;                                   // 0 slice kernels of one workgroup size, 1 fix-up of cut rows, 2 merge of column-tile
-                                                        // partial vectors, 3 transposed tile streams, 4 dense overlay (GeMV)
-        std::vector<TtsEntry> tts;                      // kind 3
-        std::vector<GemvEntry> gemv;                    // kind 4: the dense overlay handles of the call in one grid
-        std::vector<const SpmvDeviceMatrix*> parts;     // kinds 0, 1
-        std::vector<float*> ys;                         // kind 1: where each part's cut rows live (y or a partial vector)
-        std::vector<int32_t> rows;                      // kind 2
-        std::vector<uint8_t> item_tiles;                // kind 0: parts per item (> 1: the XCD-pinned column tiles of one matrix)
-        std::vector<int32_t> fix_counts;                // kind 5 (fix-up + merge in one launch): short fix entries per part; rows = merged matrices
-        void* d_table = nullptr;
-        void* d_table2 = nullptr;                       // kind 5: the TailMergeEntry table
-        int lane = 0;                                   // main launches: 0 = the caller's stream, k > 0 = side stream k - 1
-        int64_t weight = 0;                             // main launches: device bytes of the matrices in the grid
-    };
-    struct BatchPlan {
-        std::vector<uint64_t> key;
-        std::vector<BatchLaunch> launches;
-        int64_t stream_bytes = 0;     // 8 B per entry of the call's sparse matrices: decides whether side streams pay
-        int lanes = 1;                // streams the main launches are spread over
-        // The launches of a two-stream call captured once into a HIP graph and replayed.  TWO executables of the same captured
-        // graph, each with the alpha it was last patched to and an event recorded behind its last launch: a call with another
-        // alpha patches the executable that is NOT in flight (hipGraphExecKernelNodeSetParams rewrites the executable's kernel
-        // arguments in place -- patching one whose earlier launch is still queued could run that launch with the new alpha),
-        // and waits for that executable's own last launch -- two calls back -- before it touches it.
-        struct GraphSlot {
-            hipGraphExec_t exec = nullptr;
-            float alpha = 0.0f;
-            hipEvent_t done = nullptr;       // recorded on the launch stream behind the last launch of `exec`
-            bool launched = false;
-            uint64_t last_use = 0;
-        } slot[2];
-        uint64_t use_counter = 0;
-        hipGraph_t graph_src = nullptr;      // the captured graph the executables were instantiated from (kept: its node handles patch alpha)
-        int runs = 0;
-    };
-    std::vector<BatchPlan> batch_plans;
-    int64_t graph_instantiations = 0, graph_alpha_updates = 0;     // hispmv_batch_graph_stats
-    // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
-    // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
-    // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.
-    int carry_mode = 2;          // 0 fixup, 1 lookback, 2 auto (HISPMV_CARRY)
-    // COO -> CSR -> slice stream: 0 on the host (OpenMP), 1 on the device (hispmv_prep_device.hip), 2 auto = device from
-    // 2 M entries (HISPMV_PREP=host|device|auto); both give the same stream byte for byte
-    int prep_mode = 2;
-    DevicePrepTimes last_prep_times;
-    // device format of matrices whose plan gathers x through L2: 0 slice stream always, 1 transposed tile stream whenever
-    // the plan has no window, 2 auto = transposed tile stream when its gathers touch <= 32 cache lines of x per wave
-    // instruction (HISPMV_FORMAT=slices|tts|auto)
-    FormatOptions format_opts;   // HISPMV_FORMAT / _TTS_GEOMETRY / _BAND_TILES / _COL_TILE_BYTES / _TTS_MIN_NNZ (hispmv_choose.h)
-    // geometry of a transposed tile stream: 0 the 8 K-row tiles always, 1 the tall geometry (two column parts of 16 K-row
-    // tiles) for every tile stream, 2 auto (HISPMV_TTS_GEOMETRY=standard|tall|auto)
-    int n_cus = 256;
-};
-
-struct hispmv_prep {
-    Csr csr;
-    SliceStream st;
-    LaunchPlan plan;
-    TtsStream tts;
-};
 
 namespace {
 
 thread_local std::string g_create_err;
 thread_local std::string g_prep_err;
 
+}  // namespace
+
+namespace hispmv {
 int fail(hispmv_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg; else g_create_err = msg;
     return code;
@@ -178,43 +22,8 @@ int fail(hispmv_ctx* c, int code, const std::string& msg) {
 int hip_fail(hispmv_ctx* c, hipError_t e, const char* what) {
     return fail(c, HISPMV_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define HIP_TRY(c, call)                                        \
-    do {                                                        \
-        hipError_t e_ = (call);                                 \
-        if (e_ != hipSuccess) return hip_fail((c), e_, #call);  \
-    } while (0)
-
-// Every device / pinned allocation of the library is released through these: a failing free (a pointer freed twice, a
-// pointer the runtime does not know) is counted, and hispmv_free_failures() lets a test read the count.
+std::string& prep_error() { return g_prep_err; }
 std::atomic<int64_t> g_free_failures{0};
-template <class T> void dev_free(T*& p) {
-    if (p && hipFree((void*)p) != hipSuccess) { g_free_failures++; (void)hipGetLastError(); }
-    p = nullptr;
-}
-template <class T> void host_free(T*& p) {
-    if (p && hipHostFree((void*)p) != hipSuccess) { g_free_failures++; (void)hipGetLastError(); }
-    p = nullptr;
-}
-
-void free_batch_plans(hispmv_ctx* c) {
-    for (auto& p : c->batch_plans) {
-        for (auto& g : p.slot) {
-            if (g.launched && g.done) (void)hipEventSynchronize(g.done);
-            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-            if (g.done) { (void)hipEventDestroy(g.done); g.done = nullptr; }
-            g.launched = false;
-        }
-        if (p.graph_src) { (void)hipGraphDestroy(p.graph_src); p.graph_src = nullptr; }
-        for (auto& l : p.launches) { dev_free(l.d_table); dev_free(l.d_table2); }
-    }
-    c->batch_plans.clear();
-}
-
-int64_t sparse_device_bytes(const SliceStream& st, const DeviceStream& ds) {
-    return (int64_t)ds.bytes.size() + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
-           (int64_t)st.n_slices * 12 + 8;
-}
-
 // A bounded in-kernel wait that expired leaves 1 in the context's error word.
 int check_device_error(hispmv_ctx* c) {
     // callers have synchronised the stream the kernels ran on; the word lives in host memory
@@ -224,6 +33,14 @@ int check_device_error(hispmv_ctx* c) {
         return fail(c, HISPMV_EDEVICE, "carry hand-off between slices timed out (lost or overlapping launch on one handle)");
     }
     return HISPMV_OK;
+}
+}  // namespace hispmv
+
+namespace {
+
+int64_t sparse_device_bytes(const SliceStream& st, const DeviceStream& ds) {
+    return (int64_t)ds.bytes.size() + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
+           (int64_t)st.n_slices * 12 + 8;
 }
 
 void free_matrix_device(Matrix& m) {
@@ -304,9 +121,6 @@ int upload(hispmv_ctx* c, Matrix& m, const T* host, size_t count, const T** dev_
     *dev_out = (const T*)d;
     return HISPMV_OK;
 }
-
-int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float* const* d_x, const float* const* d_bias,
-                      float* const* d_y, float alpha, float beta, hipStream_t s);
 
 int launch_matrix(hispmv_ctx* c, Matrix& m, const float* d_x, const float* d_bias, float* d_y,
                   float alpha, float beta, hipStream_t s, bool fixup_only = false) {
@@ -834,448 +648,6 @@ HISPMV_API int hispmv_spmv_device(hispmv_ctx* c, int idx, const float* d_x, cons
     return launch_matrix(c, m, d_x, d_bias, d_y, alpha, beta, stream ? (hipStream_t)stream : c->stream);
 }
 
-// Builds the launches of a batch call: every column tile of every sparse handle is one "part"; parts with the same
-// workgroup size share a grid (largest first, so that the small ones fill the tail), ONE fix-up launch finishes the cut
-// rows of all parts (each on its own output: y for tile 0, the handle's partial vector for tile t > 0), ONE merge launch
-// adds the partial vectors of the column-tiled matrices to their y.
-static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t n, const int32_t* idx, const float* const* d_x,
-                            const float* const* bias, float* const* d_y, float beta) {
-    struct Ref { int i; size_t t; };
-    struct Item { std::vector<Ref> refs; int threads; int64_t slices; };
-    std::vector<Item> items;
-    std::vector<Ref> refs;
-    auto dev_of = [&](const Ref& r) -> SpmvDeviceMatrix& { return c->mats[idx[r.i]]->parts[r.t].dev; };
-    auto out_of = [&](const Ref& r) -> float* {
-        Matrix& m = *c->mats[idx[r.i]];
-        return r.t == 0 ? d_y[r.i] : m.d_ypart + (r.t - 1) * (size_t)kMaxBatch * m.rows;
-    };
-    const bool pin = !std::getenv("HISPMV_NO_XCD_PIN");
-    auto upload_table0 = [&](hispmv_ctx::BatchLaunch& l, const void* host, size_t bytes) -> int {
-        HIP_TRY(c, hipMalloc(&l.d_table, bytes));
-        HIP_TRY(c, hipMemcpy(l.d_table, host, bytes, hipMemcpyHostToDevice));
-        return HISPMV_OK;
-    };
-    {   // dense overlay handles: one grid for all of them, the largest first (the small ones fill its tail; launched one
-        // after the other, the 512..2048-wide GeMVs of cpu/run_gemv.sh cost a launch latency each: 77 us for the five
-        // sizes against 56 us of streaming)
-        std::vector<int> dense;
-        for (int i = 0; i < n; ++i) if (c->mats[idx[i]]->dense) dense.push_back(i);
-        std::stable_sort(dense.begin(), dense.end(), [&](int a, int b) {
-            const Matrix& ma = *c->mats[idx[a]]; const Matrix& mb = *c->mats[idx[b]];
-            return (int64_t)ma.rows * ma.cols > (int64_t)mb.rows * mb.cols;
-        });
-        for (size_t k0 = 0; k0 < dense.size(); k0 += kMultiMax) {
-            hispmv_ctx::BatchLaunch l;
-            l.kind = 4;
-            for (size_t k = k0; k < std::min(dense.size(), k0 + (size_t)kMultiMax); ++k) {
-                const int i = dense[k];
-                const Matrix& m = *c->mats[idx[i]];
-                l.gemv.push_back(GemvEntry{m.d_dense, d_x[i], bias[i], d_y[i], m.rows, m.cols, beta, 0});
-            }
-            plan.launches.push_back(std::move(l));
-            const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().gemv.data(), plan.launches.back().gemv.size() * sizeof(GemvEntry));
-            if (rc0 != HISPMV_OK) return rc0;
-        }
-    }
-    // (+ 1 << 24: matrices whose x the kernel keeps in the LDS -- another LDS size, another kernel instantiation)
-    auto tts_class = [](const Matrix& m) {
-        return m.parts[0].tdev.staging_floats + (m.parts.size() == 1 && tts_x_in_lds(m.parts[0].tdev, 1) ? (1 << 24) : 0) + (m.parts[0].tdev.zero_fill ? (1 << 25) : 0);
-    };
-    std::vector<int> tts_classes;                // staging size = the geometry (hispmv_tts.h): small 13 K, standard 28 K, tall 23 K, paired 11 K
-    for (int i = 0; i < n; ++i) {
-        const Matrix& m = *c->mats[idx[i]];
-        if (m.dense || m.format != 1) continue;
-        const int cls = tts_class(m);
-        if (std::find(tts_classes.begin(), tts_classes.end(), cls) == tts_classes.end()) tts_classes.push_back(cls);
-    }
-    std::sort(tts_classes.begin(), tts_classes.end());
-    for (const int geometry : tts_classes) {
-        // transposed tile streams: their row tiles share one grid per geometry (the launch's workgroup size and LDS size
-        // are those of its entries: tiles of different geometries must not ride together)
-        hispmv_ctx::BatchLaunch l;
-        l.kind = 3;
-        auto flush = [&]() -> int {
-            if (l.tts.empty()) return HISPMV_OK;
-            plan.launches.push_back(std::move(l));
-            const int rc0 = upload_table0(plan.launches.back(), plan.launches.back().tts.data(), plan.launches.back().tts.size() * sizeof(TtsEntry));
-            l = hispmv_ctx::BatchLaunch{};
-            l.kind = 3;
-            return rc0;
-        };
-        std::vector<int> order;                  // matrices with the longest tiles first (a CU holds one tile at a time)
-        for (int i = 0; i < n; ++i) {
-            const Matrix& m = *c->mats[idx[i]];
-            if (m.dense || m.format != 1) continue;
-            if (tts_class(m) == geometry) order.push_back(i);
-        }
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            const Matrix& ma = *c->mats[idx[a]]; const Matrix& mb = *c->mats[idx[b]];
-            return ma.n_elems / std::max(1, ma.parts[0].tdev.n_tiles) > mb.n_elems / std::max(1, mb.parts[0].tdev.n_tiles);
-        });
-        for (int i : order) {
-            Matrix& m = *c->mats[idx[i]];
-            if (l.tts.size() + m.parts.size() > (size_t)kMultiMax) { const int rc0 = flush(); if (rc0 != HISPMV_OK) return rc0; }
-            // the column parts of a tall-geometry matrix: one item, pinned to XCD subsets (part 0 writes y with the bias,
-            // part t > 0 alpha*A_t*x into the handle's partial vector: the merge launch adds it)
-            const bool pinned = pin && (m.parts.size() == 2 || m.parts.size() == 4);
-            for (size_t t = 0; t < m.parts.size(); ++t) {
-                l.tts.push_back(TtsEntry{m.parts[t].tdev, d_x[i], t == 0 ? bias[i] : nullptr, out_of(Ref{i, t}), t == 0 ? beta : 0.0f, 0});
-                if (t == 0) l.weight += m.n_slices * (int64_t)kWideSliceBytes * 5 / 2;
-                if (!pinned) l.item_tiles.push_back(1);
-            }
-            if (pinned) l.item_tiles.push_back((uint8_t)m.parts.size());
-        }
-        const int rc0 = flush();
-        if (rc0 != HISPMV_OK) return rc0;
-    }
-    for (int i = 0; i < n; ++i) {
-        const Matrix& m = *c->mats[idx[i]];
-        if (m.dense || m.format == 1) continue;
-        if (m.l2_tiles && pin) {                 // the L2-sized column tiles of a matrix: one item, pinned to XCD subsets
-            Item it{{}, m.parts[0].dev.block_threads, 0};
-            for (size_t t = 0; t < m.parts.size(); ++t) { it.refs.push_back(Ref{i, t}); it.slices += m.parts[t].dev.n_slices; }
-            items.push_back(std::move(it));
-        } else {
-            for (size_t t = 0; t < m.parts.size(); ++t) items.push_back(Item{{Ref{i, t}}, m.parts[t].dev.block_threads, m.parts[t].dev.n_slices});
-        }
-    }
-    std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) {
-        if (a.threads != b.threads) return a.threads > b.threads;
-        return a.slices > b.slices;
-    });
-    const size_t first_slice_launch = plan.launches.size();
-    for (const Item& it : items) for (const Ref& r : it.refs) refs.push_back(r);
-    auto upload_table = [&](hispmv_ctx::BatchLaunch& l, const void* host, size_t bytes) -> int {
-        HIP_TRY(c, hipMalloc(&l.d_table, bytes));
-        HIP_TRY(c, hipMemcpy(l.d_table, host, bytes, hipMemcpyHostToDevice));
-        return HISPMV_OK;
-    };
-    int rc;
-    for (size_t k = 0; k < items.size();) {                     // slice kernels, one launch per class
-        const int threads = items[k].threads;
-        hispmv_ctx::BatchLaunch l;
-        l.kind = 0;
-        std::vector<MultiEntry> entries;
-        while (k < items.size() && items[k].threads == threads && entries.size() + items[k].refs.size() <= (size_t)kMultiMax) {
-            for (const Ref& r : items[k].refs) {
-                SpmvDeviceMatrix& d = dev_of(r);
-                MultiEntry e{};
-                e.words = d.words; e.hdr = d.hdr; e.groups = d.groups; e.frags = d.frags;
-                e.x = d_x[r.i]; e.bias = r.t == 0 ? bias[r.i] : nullptr; e.y = out_of(r); e.carry = d.carry;
-                e.n_slices = d.n_slices; e.group_slices = d.group_slices; e.lds_floats = d.lds_floats; e.ytile_floats = d.ytile_floats;
-                e.cols = d.cols; e.rows = d.rows;
-                e.beta = r.t == 0 ? beta : 0.0f;
-                entries.push_back(e);
-                l.parts.push_back(&d);
-            }
-            l.item_tiles.push_back((uint8_t)items[k].refs.size());
-            ++k;
-        }
-        plan.launches.push_back(std::move(l));
-        if ((rc = upload_table(plan.launches.back(), entries.data(), entries.size() * sizeof(MultiEntry))) != HISPMV_OK) return rc;
-    }
-    // Launch order = stream assignment (main launch k goes to lane k mod lanes, hispmv_spmv_device_batch).  HISPMV_BATCH_ORDER=
-    // small_first: the slice grids of SMALL workgroups first (256 threads, then 512, 1024), ahead of the tile streams: a
-    // 256-thread workgroup (4 wavefronts, a few KiB of LDS) fits on a CU NEXT TO a 1024-thread slice workgroup (91 VGPRs: five
-    // wavefronts per SIMD; windows of <= 115 KiB), so launched together the two grids share CUs -- the small matrices' L2
-    // gathers ride under the HBM-bound stream of the large ones -- while a tile (145 KiB, 16 x 126 VGPRs) shares with nobody.
-    if (c->batch_order == 1) {
-        std::vector<hispmv_ctx::BatchLaunch> slices(std::make_move_iterator(plan.launches.begin() + (long)first_slice_launch),
-                                                    std::make_move_iterator(plan.launches.end()));
-        plan.launches.erase(plan.launches.begin() + (long)first_slice_launch, plan.launches.end());
-        std::reverse(slices.begin(), slices.end());
-        // small slice grids, then the large ones, then whatever was there before (dense, tile streams)
-        std::vector<hispmv_ctx::BatchLaunch> rest = std::move(plan.launches);
-        plan.launches.clear();
-        for (auto& l : slices) plan.launches.push_back(std::move(l));
-        for (auto& l : rest) plan.launches.push_back(std::move(l));
-    }
-    std::vector<Ref> fixrefs = refs;                            // + tile streams that cut long rows into pieces
-    for (int i = 0; i < n; ++i) {
-        const Matrix& m = *c->mats[idx[i]];
-        if (!m.dense && m.format == 1)
-            for (size_t t = 0; t < m.parts.size(); ++t) if (m.parts[t].tdev.n_fix > 0) fixrefs.push_back(Ref{i, t});
-    }
-    // Lanes of the main launches: round-robin in launch order, and the lane with the most (time-weighted) bytes is the CALLER'S
-    // stream with its launches ENQUEUED FIRST (HISPMV_BATCH_LANES=rr: plain round-robin), so that the tail launch follows the
-    // last-finishing chain on the same queue instead of behind a cross-queue dependency.  Replayed as a graph the runtime
-    // keeps the chain of the FIRST captured root on the launch stream's queue: with the 1024-thread slice grid captured first
-    // (the structured set, where it finishes last) the tail starts 6.7 us behind its end instead of 12 (kernel timelines in
-    // profiles/r3_experiments/step_structure.json): 0.288-0.294 against 0.291-0.299 ms per step; in the pessimistic family
-    // the tile streams are the heavier chain and the order stays what it was.  (Measured and dropped: longest-processing-time
-    // assignment -- the 256-thread grid then follows the 1024-thread one and the pessimistic family loses 1-4 %; the heavy
-    // lane on the caller's stream but captured second: 0.302-0.303.)
-    {
-        plan.lanes = plan.stream_bytes >= c->batch_streams_min_bytes ? c->batch_streams : 1;
-        std::vector<hispmv_ctx::BatchLaunch*> mains;
-        for (auto& l : plan.launches) {
-            if (l.kind == 0) for (const SpmvDeviceMatrix* d : l.parts) l.weight += d->n_slices * (int64_t)kWideSliceBytes;
-            // (a tile stream runs at ~2.5 TB/s against ~6.5 for a slice stream: its bytes count 2.5-fold; set when the entries were made)
-            if (l.kind == 4) for (const GemvEntry& e : l.gemv) l.weight += 4 * (int64_t)e.rows * e.cols;
-            mains.push_back(&l);
-        }
-        plan.lanes = std::max(1, std::min<int>(plan.lanes, (int)mains.size()));
-        // round-robin in launch order (tile streams, 1024-thread slices, 256-thread slices, ...) ...
-        int k = 0;
-        for (hispmv_ctx::BatchLaunch* l : mains) l->lane = k++ % plan.lanes;
-        if (c->batch_lanes_heavy_first && plan.lanes >= 2) {
-            // ... and the lane with the most (time-weighted) bytes becomes the caller's stream, its launches enqueued first
-            std::vector<int64_t> load((size_t)plan.lanes, 0);
-            for (hispmv_ctx::BatchLaunch* l : mains) load[(size_t)l->lane] += l->weight;
-            const int heavy = (int)(std::max_element(load.begin(), load.end()) - load.begin());
-            for (hispmv_ctx::BatchLaunch* l : mains) l->lane = l->lane == heavy ? 0 : l->lane == 0 ? heavy : l->lane;
-            std::stable_sort(plan.launches.begin(), plan.launches.end(), [](const hispmv_ctx::BatchLaunch& x, const hispmv_ctx::BatchLaunch& y) { return x.lane < y.lane; });
-        }
-    }
-    // The tail: ONE launch that finishes the cut rows and merges the partial vectors of column-tiled matrices (which then
-    // apply their own fix-ups) when every tiled matrix of the call carries its row -> fix table and the tables fit one
-    // launch; otherwise a fix-up launch and a merge launch.
-    std::vector<int> tiled;
-    bool fused = !std::getenv("HISPMV_NO_FUSED_TAIL");
-    for (int i = 0; i < n; ++i) {
-        const Matrix& m = *c->mats[idx[i]];
-        if (m.dense || m.parts.size() < 2) continue;
-        tiled.push_back(i);
-        fused = fused && m.d_fix_of_row != nullptr;
-    }
-    if (fused) {
-        std::vector<Ref> plain;                                 // parts whose cut rows the fix-up blocks finish
-        for (const Ref& r : fixrefs) if (c->mats[idx[r.i]]->parts.size() < 2) plain.push_back(r);
-        fused = plain.size() <= (size_t)kMultiMax && tiled.size() <= (size_t)kMultiMax;
-        if (fused) {
-            hispmv_ctx::BatchLaunch l;
-            l.kind = 5;
-            std::vector<MultiFixEntry> fix;
-            std::vector<TailMergeEntry> mrg;
-            bool any = !tiled.empty();
-            for (const Ref& r : plain) {
-                SpmvDeviceMatrix& d = dev_of(r);
-                fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(r), d.n_fix_short, 0});
-                l.fix_counts.push_back(d.n_fix_short);
-                l.parts.push_back(&d); l.ys.push_back(out_of(r));               // (long chains: their own launches behind the tail)
-                any = any || d.n_fix_short > 0 || d.n_fix_long > 0;
-            }
-            for (int i : tiled) {
-                Matrix& m = *c->mats[idx[i]];
-                TailMergeEntry e{};
-                e.y = d_y[i]; e.parts = m.d_ypart; e.part_stride = (long long)kMaxBatch * m.rows; e.n_parts = (int32_t)m.parts.size() - 1; e.rows = m.rows;
-                e.fix_of_row = m.d_fix_of_row;
-                for (size_t t = 0; t < m.parts.size(); ++t) { e.fix[t] = m.parts[t].dev.fix_short; e.carry[t] = m.parts[t].dev.carry; }
-                mrg.push_back(e);
-                l.rows.push_back(m.rows);
-            }
-            if (!any) return HISPMV_OK;
-            plan.launches.push_back(std::move(l));
-            hispmv_ctx::BatchLaunch& L = plan.launches.back();
-            if (!fix.empty() && (rc = upload_table(L, fix.data(), fix.size() * sizeof(MultiFixEntry))) != HISPMV_OK) return rc;
-            if (!mrg.empty()) {
-                HIP_TRY(c, hipMalloc(&L.d_table2, mrg.size() * sizeof(TailMergeEntry)));
-                HIP_TRY(c, hipMemcpy(L.d_table2, mrg.data(), mrg.size() * sizeof(TailMergeEntry), hipMemcpyHostToDevice));
-            }
-            return HISPMV_OK;
-        }
-    }
-    for (size_t k = 0; k < fixrefs.size(); k += kMultiMax) {    // fix-up of the cut rows
-        hispmv_ctx::BatchLaunch l;
-        l.kind = 1;
-        std::vector<MultiFixEntry> fix;
-        bool any = false;
-        for (size_t q = k; q < std::min(fixrefs.size(), k + kMultiMax); ++q) {
-            SpmvDeviceMatrix& d = dev_of(fixrefs[q]);
-            fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(fixrefs[q]), d.n_fix_short, 0});
-            l.parts.push_back(&d);
-            l.ys.push_back(out_of(fixrefs[q]));
-            any = any || d.n_fix_short > 0 || d.n_fix_long > 0;
-        }
-        if (!any) continue;
-        plan.launches.push_back(std::move(l));
-        if ((rc = upload_table(plan.launches.back(), fix.data(), fix.size() * sizeof(MultiFixEntry))) != HISPMV_OK) return rc;
-    }
-    std::vector<MultiMergeEntry> merges;
-    std::vector<int32_t> merge_rows;
-    auto flush_merges = [&]() -> int {
-        if (merges.empty()) return HISPMV_OK;
-        hispmv_ctx::BatchLaunch l;
-        l.kind = 2; l.rows = merge_rows;
-        plan.launches.push_back(std::move(l));
-        const int r2 = upload_table(plan.launches.back(), merges.data(), merges.size() * sizeof(MultiMergeEntry));
-        merges.clear(); merge_rows.clear();
-        return r2;
-    };
-    for (int i : tiled) {                                       // merge of the column-tile partial vectors
-        Matrix& m = *c->mats[idx[i]];
-        merges.push_back(MultiMergeEntry{d_y[i], m.d_ypart, (long long)kMaxBatch * m.rows, (int32_t)m.parts.size() - 1, m.rows});
-        merge_rows.push_back(m.rows);
-        if ((int)merges.size() == kMultiMax && (rc = flush_merges()) != HISPMV_OK) return rc;
-    }
-    return flush_merges();
-}
-
-HISPMV_API int hispmv_spmv_device_batch(hispmv_ctx* c, int32_t n, const int32_t* idx, const float* const* d_x,
-                                        const float* const* d_bias, float* const* d_y, float alpha, float beta, void* stream) {
-    if (!c) return HISPMV_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (stream) c->user_stream = (hipStream_t)stream;
-    return spmv_batch_locked(c, n, idx, d_x, d_bias, d_y, alpha, beta, stream ? (hipStream_t)stream : c->stream);
-}
-
-namespace {
-int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float* const* d_x, const float* const* d_bias,
-                      float* const* d_y, float alpha, float beta, hipStream_t s) {
-    if (n < 0 || (n > 0 && (!idx || !d_x || !d_y || (beta != 0.0f && !d_bias)))) return fail(c, HISPMV_EINVAL, "NULL argument");
-    for (int i = 0; i < n; ++i) {
-        if (idx[i] < 0 || idx[i] >= (int)c->mats.size()) return fail(c, HISPMV_EINVAL, "Matrix idx out of range");
-        const Matrix& m = *c->mats[idx[i]];
-        if (!m.loaded) return fail(c, HISPMV_ESTATE, "spmv_device_batch called before load_matrices");
-        if (!d_x[i] || !d_y[i] || (beta != 0.0f && !d_bias[i])) return fail(c, HISPMV_EINVAL, "NULL device vector");
-        for (int k = 0; k < i; ++k) {
-            if (d_y[k] == d_y[i]) return fail(c, HISPMV_EINVAL, "two matrices of a batch write the same y");
-            // the carry buffers of cut rows belong to the handle: one SpMV per handle at a time (hispmv.h, threading)
-            if (idx[k] == idx[i] && !m.dense) return fail(c, HISPMV_EINVAL, "the same sparse handle twice in one batch");
-        }
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
-    const float* const* bias = d_bias;
-    std::vector<const float*> no_bias;
-    if (!bias) { no_bias.assign((size_t)n, nullptr); bias = no_bias.data(); }
-    // the launches of this call signature: built once, replayed afterwards (beta enters the tables; alpha is a kernel argument)
-    std::vector<uint64_t> key{(uint64_t)n, (uint64_t)__builtin_bit_cast(uint32_t, beta)};
-    for (int i = 0; i < n; ++i) {
-        key.push_back((uint64_t)idx[i]); key.push_back((uint64_t)(uintptr_t)d_x[i]);
-        key.push_back((uint64_t)(uintptr_t)(beta != 0.0f ? bias[i] : nullptr)); key.push_back((uint64_t)(uintptr_t)d_y[i]);
-    }
-    hispmv_ctx::BatchPlan* plan = nullptr;
-    for (auto& p : c->batch_plans) if (p.key == key) { plan = &p; break; }
-    if (!plan) {
-        if (c->batch_plans.size() >= 16) free_batch_plans(c);      // callers that keep changing their vectors: start over
-        c->batch_plans.emplace_back();
-        c->batch_plans.back().key = key;
-        for (int i = 0; i < n; ++i) {
-            const Matrix& mi = *c->mats[idx[i]];
-            c->batch_plans.back().stream_bytes += mi.dense ? 4 * (int64_t)mi.rows * mi.cols : 8 * mi.nnz;
-        }
-        const int rc = build_batch_plan(c, c->batch_plans.back(), n, idx, d_x, bias, d_y, beta);
-        if (rc != HISPMV_OK) {                                      // nothing half-built stays behind
-            for (auto& l : c->batch_plans.back().launches) { dev_free(l.d_table); dev_free(l.d_table2); }
-            c->batch_plans.pop_back();
-            return rc;
-        }
-        plan = &c->batch_plans.back();
-    }
-    // main launches (kinds 0 and 3) are independent of each other: spread over the caller's stream and the side streams;
-    // the fix-up and merge launches follow on the caller's stream behind a join
-    const int lanes = plan->lanes;
-    // the launches, as one function of the stream: main launches spread over the caller's stream and the side streams (forked
-    // from / joined to it with events), fix-up and merge behind the join
-    auto enqueue = [&]() -> int {
-        if (lanes > 1) {
-            HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-            for (int i = 0; i + 1 < lanes; ++i) HIP_TRY(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-        }
-        bool joined = lanes <= 1;
-        for (const auto& l : plan->launches) {
-            hipError_t e = hipSuccess;
-            const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
-            hipStream_t ls = s;
-            if (is_main && lanes > 1) ls = l.lane == 0 ? s : c->side[l.lane - 1];
-            if (!is_main && !joined) {
-                for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
-                joined = true;
-            }
-            if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
-            else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const TtsEntry*)l.d_table, alpha, ls);
-            else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
-            else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
-            else if (l.kind == 5) {
-                e = launch_tail_multi(l.fix_counts.data(), (int)l.fix_counts.size(), (const MultiFixEntry*)l.d_table, l.rows.data(), (int)l.rows.size(),
-                                      (const TailMergeEntry*)l.d_table2, alpha, ls);
-                for (size_t q = 0; e == hipSuccess && q < l.parts.size(); ++q)       // rows that span more than 32 slices: a wavefront per row
-                    if (l.parts[q]->n_fix_long > 0) e = launch_fixup_long(*l.parts[q], l.ys[q], alpha, ls);
-            }
-            else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
-            if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : l.kind == 5 ? "launch_tail_multi" : "launch_merge_multi");
-        }
-        if (!joined)
-            for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
-        return HISPMV_OK;
-    };
-    // A two-stream call is captured into a HIP graph the second time its signature is seen (the first run sets the
-    // kernels' attributes) and replayed from then on: the set's step 0.315-0.320 -> 0.309-0.310 ms -- the fork/join events
-    // of the two streams become graph edges.  HISPMV_BATCH_GRAPH=0 switches it off; a stream that is being captured by the
-    // caller, or a capture the runtime refuses, falls back to plain launches.
-    // (a stream the CALLER is capturing takes plain launches: they become nodes of the caller's graph; replaying the library's
-    // own graph into a capture recorded nothing on this runtime)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool caller_captures = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-    (void)hipGetLastError();
-    if (c->batch_graphs && lanes > 1 && !caller_captures) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
-        using Slot = hispmv_ctx::BatchPlan::GraphSlot;
-        auto drop_graphs = [&]() {
-            for (Slot& g : plan->slot) {
-                if (g.launched && g.done) (void)hipEventSynchronize(g.done);
-                if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-                g.launched = false;
-            }
-            if (plan->graph_src) { (void)hipGraphDestroy(plan->graph_src); plan->graph_src = nullptr; }
-        };
-        auto launch_slot = [&](Slot& g) -> bool {
-            if (hipGraphLaunch(g.exec, s) != hipSuccess) { (void)hipGetLastError(); return false; }
-            if (!g.done && hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g.done = nullptr; }
-            // (without the event the executable can never be patched safely: its alpha stays what it is, see below)
-            g.launched = g.done && hipEventRecord(g.done, s) == hipSuccess;
-            if (!g.launched) (void)hipGetLastError();
-            g.last_use = ++plan->use_counter;
-            return true;
-        };
-        if (plan->graph_src) {
-            // 1. an executable that already carries this alpha
-            Slot* pick = nullptr;
-            for (Slot& g : plan->slot) if (g.exec && g.alpha == alpha) { pick = &g; break; }
-            if (!pick) {
-                // 2. another alpha on the same call: no capture -- a second executable of the captured graph the first time,
-                //    afterwards the executable used longest ago, patched once ITS last launch has completed
-                Slot* victim = nullptr;
-                for (Slot& g : plan->slot) if (!g.exec) { victim = &g; break; }
-                if (victim) {
-                    if (hipGraphInstantiate(&victim->exec, plan->graph_src, nullptr, nullptr, 0) == hipSuccess) { c->graph_instantiations++; victim->launched = false; }
-                    else { (void)hipGetLastError(); victim->exec = nullptr; victim = nullptr; }
-                }
-                if (!victim) victim = plan->slot[0].last_use <= plan->slot[1].last_use ? &plan->slot[0] : &plan->slot[1];
-                bool ok = victim->exec != nullptr;
-                if (ok && victim->launched) ok = victim->done && hipEventSynchronize(victim->done) == hipSuccess;
-                if (ok) ok = graph_set_alpha(victim->exec, plan->graph_src, alpha) == hipSuccess;
-                if (ok) { victim->alpha = alpha; c->graph_alpha_updates++; pick = victim; }
-                else (void)hipGetLastError();
-            }
-            if (pick && launch_slot(*pick)) return HISPMV_OK;
-            drop_graphs();
-        }
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (plan->runs >= 1 && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone &&
-            hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int rc = enqueue();
-            hipGraph_t g = nullptr;
-            const hipError_t e_end = hipStreamEndCapture(s, &g);
-            if (rc != HISPMV_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-            drop_graphs();
-            hipError_t e = e_end;
-            Slot& g0 = plan->slot[0];
-            if (e == hipSuccess) e = hipGraphInstantiate(&g0.exec, g, nullptr, nullptr, 0);
-            if (e == hipSuccess) c->graph_instantiations++;
-            plan->graph_src = g;
-            if (e == hipSuccess) { g0.alpha = alpha; g0.launched = false; if (launch_slot(g0)) return HISPMV_OK; }
-            (void)hipGetLastError();
-            drop_graphs();
-            c->batch_graphs = false;               // this runtime / stream does not take it: plain launches from here on
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    plan->runs++;
-    return enqueue();
-}
-}  // namespace
-
 HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
     if (!c) return HISPMV_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1291,13 +663,6 @@ HISPMV_API int hispmv_synchronize(hispmv_ctx* c) {
 }
 
 HISPMV_API float hispmv_last_kernel_ms(hispmv_ctx* c) { return c ? c->last_ms : -1.0f; }
-
-HISPMV_API int hispmv_batch_graph_stats(hispmv_ctx* c, int64_t out[2]) {
-    if (!c || !out) return HISPMV_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
-    out[0] = c->graph_instantiations; out[1] = c->graph_alpha_updates;
-    return HISPMV_OK;
-}
 
 HISPMV_API float hispmv_time_device(hispmv_ctx* c, int idx, const float* d_x, const float* d_bias, float* d_y,
                                     float alpha, float beta, int reps) {
@@ -1332,161 +697,3 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     return HISPMV_OK;
 }
 
-// ---- host-only preprocessor access ---------------------------------------------------------------
-HISPMV_API const char* hispmv_prep_last_error(void) { return g_prep_err.c_str(); }
-
-HISPMV_API int hispmv_host_threads(void) { return host_threads(); }
-
-HISPMV_API int hispmv_prep_from_coo(hispmv_prep** out, const int32_t* r, const int32_t* cl, const float* v,
-                                    int64_t nnz, int32_t rows, int32_t cols) {
-    if (!out) return HISPMV_EINVAL;
-    host_threads();
-    *out = nullptr;
-    if (rows <= 0 || cols <= 0 || nnz < 0) { g_prep_err = "bad sparse matrix arguments"; return HISPMV_EINVAL; }
-    try {
-        auto p = std::make_unique<hispmv_prep>();
-        p->csr = coo_to_csr(rows, cols, nnz, r, cl, v);
-        p->st = build_stream(p->csr);
-        *out = p.release();
-        return HISPMV_OK;
-    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
-}
-
-HISPMV_API int hispmv_prep_from_coo_device(hispmv_prep** out, int device_id, const int32_t* r, const int32_t* cl, const float* v,
-                                           int64_t nnz, int32_t rows, int32_t cols, double seconds[5]) {
-    if (!out) return HISPMV_EINVAL;
-    *out = nullptr;
-    if (rows <= 0 || cols <= 0 || nnz < 0 || (nnz > 0 && (!r || !cl || !v))) { g_prep_err = "bad sparse matrix arguments"; return HISPMV_EINVAL; }
-    if (hipSetDevice(device_id) != hipSuccess) { g_prep_err = "no such HIP device"; return HISPMV_EDEVICE; }
-    try {
-        auto p = std::make_unique<hispmv_prep>();
-        DevicePrepTimes t;
-        std::string err;
-        if (!prep_on_device(rows, cols, nnz, r, cl, v, p->csr, p->st, t, err)) {
-            g_prep_err = err;
-            return err.find("outside") != std::string::npos || err.find("dimension") != std::string::npos ? HISPMV_EINVAL : HISPMV_EDEVICE;
-        }
-        if (seconds) { seconds[0] = t.upload; seconds[1] = t.csr_device; seconds[2] = t.offsets_host; seconds[3] = t.stream_device; seconds[4] = t.download; }
-        *out = p.release();
-        return HISPMV_OK;
-    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
-}
-
-HISPMV_API int hispmv_prep_from_mtx(hispmv_prep** out, const char* path, int flavor) {
-    host_threads();
-    if (!out) return HISPMV_EINVAL;
-    *out = nullptr;
-    if (!path || (flavor != 0 && flavor != 1)) { g_prep_err = "bad arguments"; return HISPMV_EINVAL; }
-    try {
-        Coo coo = read_mtx(path, (MtxFlavor)flavor);
-        auto p = std::make_unique<hispmv_prep>();
-        p->csr = coo_to_csr(coo.rows, coo.cols, (int64_t)coo.r.size(), coo.r.data(), coo.c.data(), coo.v.data());
-        p->st = build_stream(p->csr);
-        *out = p.release();
-        return HISPMV_OK;
-    } catch (const std::runtime_error& ex) { g_prep_err = ex.what(); return HISPMV_EIO;
-    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
-}
-
-HISPMV_API void hispmv_prep_free(hispmv_prep* p) { delete p; }
-
-// The format / tiling decision of the loader for this matrix on a device with n_cus compute units, host-only
-// (hispmv_choose.cpp: the same function hispmv_create_sparse_handle* calls).  Works on a copy of the prepared CSR.
-HISPMV_API int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_t out[16]) {
-    if (!p || !out || n_cus <= 0) return HISPMV_EINVAL;
-    try {
-        Csr copy = p->csr;
-        FormatOptions opt = FormatOptions::from_env();
-        opt.decide_only = true;
-        const FormatChoice ch = choose_format(std::move(copy), nullptr, n_cus, opt);
-        int64_t n_slices = 0, n_elems = 0, n_split = 0, global_elems = 0;
-        for (const HostPart& q : ch.parts) {
-            if (q.is_tts) { n_slices += (int64_t)q.tts.col_base.size(); n_elems += q.tts.nnz + q.tts.n_fillers; n_split += (int64_t)q.tts.fix.size() / 4; }
-            else { n_slices += q.st.n_slices; n_elems += q.st.n_elems; n_split += (int64_t)q.st.fix.size(); global_elems += q.plan.lds_floats > 0 ? q.plan.global_elems : q.st.n_slices * (int64_t)kSliceElems; }
-        }
-        const HostPart& p0 = ch.parts[0];
-        out[0] = ch.format; out[1] = ch.parts.size() > 1 ? (ch.tile_kind ? ch.tile_kind : 1) : 0; out[2] = (int64_t)ch.parts.size();
-        out[3] = ch.col_tile_width; out[4] = ch.col_tile_base; out[5] = ch.l2_tiles ? 1 : 0;
-        out[6] = ch.format == 1 ? p0.tts.geometry.threads : p0.plan.block_threads;
-        out[7] = ch.format == 1 ? p0.tts.geometry.max_slots / kTtsChunk : p0.plan.group_slices;
-        out[8] = ch.format == 1 ? 0 : p0.plan.lds_floats;
-        out[9] = n_slices; out[10] = n_elems; out[11] = n_split;
-        out[12] = (int64_t)(ch.tts_lines_per_gather * 1000.0 + 0.5);
-        out[13] = global_elems;        // elements that gather x through L2 (slice streams: outside their window, or no window at all)
-        out[14] = 0; out[15] = 0;
-        return HISPMV_OK;
-    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
-}
-
-HISPMV_API int hispmv_prep_dims(const hispmv_prep* p, int64_t d[8]) {
-    if (!p || !d) return HISPMV_EINVAL;
-    d[0] = p->st.rows; d[1] = p->st.cols; d[2] = p->st.nnz; d[3] = p->st.n_elems; d[4] = p->st.n_slices;
-    d[5] = kSliceElems; d[6] = (int64_t)p->st.fix.size(); d[7] = p->st.bytes();
-    return HISPMV_OK;
-}
-HISPMV_API int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]) {
-    if (!p || !plan || n_cus <= 0) return HISPMV_EINVAL;
-    SliceStream copy = p->st;                      // make_plan rewrites the words of staged groups
-    const LaunchPlan g = make_plan(copy, n_cus);
-    plan[0] = g.block_threads; plan[1] = g.group_slices; plan[2] = g.lds_floats; plan[3] = g.ytile_floats;
-    plan[4] = (int64_t)g.groups.size();
-    plan[5] = ((int64_t)g.lds_floats + (int64_t)g.ytile_floats * (g.block_threads / 64)) * 4;
-    return HISPMV_OK;
-}
-
-HISPMV_API int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[2]) {
-    if (!p || !counts || n_cus <= 0) return HISPMV_EINVAL;
-    p->plan = make_plan(p->st, n_cus);
-    counts[0] = (int64_t)p->plan.groups.size(); counts[1] = (int64_t)p->plan.frags.size();
-    return HISPMV_OK;
-}
-HISPMV_API const int32_t* hispmv_prep_groups(const hispmv_prep* p) { return (const int32_t*)p->plan.groups.data(); }
-HISPMV_API const int32_t* hispmv_prep_frags(const hispmv_prep* p) { return (const int32_t*)p->plan.frags.data(); }
-
-HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int small_geometry, int64_t counts[8], double* lines_per_gather) {
-    if (!p || !counts) return HISPMV_EINVAL;
-    try {
-        TtsGeometry geo;
-        if (small_geometry == 1) { geo.max_slots = kTtsSmallSlots; geo.max_rows = kTtsSmallRows; geo.tiles_wanted = 512; }
-        if (small_geometry == 6) geo.zero_fill = true;      // the standard sizes without filler words (HISPMV_TTS_GEOMETRY=zerofill)
-        if (small_geometry >= 2 && small_geometry < 6) {         // 2 + q / 4 + q: column part q of the tall / paired geometry, as the loader builds it for a 256-CU device
-            const bool paired = small_geometry >= 4;
-            const int q = small_geometry - (paired ? 4 : 2);
-            if (q >= kTtsTallParts) { g_prep_err = "no such column part"; return HISPMV_EINVAL; }
-            const std::vector<int32_t> cuts = tts_column_cuts(p->csr, kTtsTallParts);
-            const Csr part = csr_column_range(p->csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? p->csr.cols : cuts[(size_t)q]);
-            p->tts = build_tts(part, target_tile_elems, paired ? tts_paired_geometry(256) : tts_tall_geometry(256, kTtsTallParts));
-        } else
-        p->tts = build_tts(p->csr, target_tile_elems, geo);
-    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
-    const TtsStream& t = p->tts;
-    counts[0] = (int64_t)t.tiles.size(); counts[1] = (int64_t)t.blocks.size(); counts[2] = (int64_t)t.col_base.size();
-    counts[3] = (int64_t)t.chunk_info.size() / 2; counts[4] = t.n_fillers; counts[5] = t.n_pad_words; counts[6] = t.max_rows; counts[7] = t.max_slots;
-    if (lines_per_gather) *lines_per_gather = t.lines_per_gather;
-    return HISPMV_OK;
-}
-HISPMV_API int hispmv_prep_tts_pieces(const hispmv_prep* p, int64_t counts[2]) {
-    if (!p || !counts) return HISPMV_EINVAL;
-    counts[0] = (int64_t)p->tts.fix.size() / 4; counts[1] = p->tts.n_carry;
-    return HISPMV_OK;
-}
-HISPMV_API const void* hispmv_prep_tts_array(const hispmv_prep* p, int which) {
-    if (!p) return nullptr;
-    switch (which) {
-        case 6: return p->tts.fix.data();
-        case 0: return p->tts.words.data();
-        case 1: return p->tts.col_base.data();
-        case 2: return p->tts.flags.data();
-        case 3: return p->tts.chunk_info.data();
-        case 4: return p->tts.tiles.data();
-        case 5: return p->tts.blocks.data();
-        default: return nullptr;
-    }
-}
-
-HISPMV_API const int64_t* hispmv_prep_csr_row_ptr(const hispmv_prep* p) { return p->csr.row_ptr.data(); }
-HISPMV_API const int32_t* hispmv_prep_csr_col(const hispmv_prep* p) { return p->csr.col.data(); }
-HISPMV_API const float* hispmv_prep_csr_val(const hispmv_prep* p) { return p->csr.val.data(); }
-HISPMV_API const uint64_t* hispmv_prep_words(const hispmv_prep* p) { return p->st.words.data(); }
-HISPMV_API const int32_t* hispmv_prep_slice_hdr(const hispmv_prep* p) { return (const int32_t*)p->st.hdr.data(); }
-HISPMV_API const int32_t* hispmv_prep_fix(const hispmv_prep* p) { return (const int32_t*)p->st.fix.data(); }

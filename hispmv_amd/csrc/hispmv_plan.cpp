@@ -128,6 +128,10 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
     bool have = false;
     Cfg chosen{256, 8, 0, 4};
     int64_t chosen_G = 8;
+    double chosen_avg_window = 0, small_cost = 1e300;
+    bool have_small = false;
+    Cfg small{512, 16, 0, 2};
+    int64_t small_G = 16;
     int cfg_index = -1;
     for (const Cfg& c0 : cfgs) {
         ++cfg_index;
@@ -184,8 +188,16 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         const double cost = ((double)staged_blocks + (double)global_elems + 0.15 * (double)two_way_elems) / ((double)n * kSliceElems) +
                             0.2 * staged_ratio + unhidden +
                             0.3 * std::max(0, 16 - waves) / 16.0;
-        if (cost < best_cost && cost < 0.8) { best_cost = cost; have = true; chosen = c; chosen_G = G; }
+        if (cost < best_cost && cost < 0.8) { best_cost = cost; have = true; chosen = c; chosen_G = G; chosen_avg_window = (double)staged_blocks * kFragBlock / (double)ng; }
+        // (experiment, HISPMV_PLAN_CORESIDE_KIB: the best of the two-per-CU 512-thread plans, kept aside)
+        if ((cfg_index == 1 || cfg_index == 2) && cost < small_cost && cost < 0.8) { small_cost = cost; have_small = true; small = c; small_G = G; }
     }
+    // Experiment (selective co-residency): a matrix whose natural plan is a 1024-thread workgroup with a SMALL
+    // window (<= HISPMV_PLAN_CORESIDE_KIB on average) takes the best 512-thread / two-per-CU plan instead (<= 48 KiB of window +
+    // 32 KiB of row tiles), so that its workgroups fit on a CU NEXT TO an 8-wavefront tile of a paired tile stream (78 KiB);
+    // matrices with large windows (PFlow_742, mouse_gene) keep their plans.  Off by default.
+    static const int coreside_kib = std::getenv("HISPMV_PLAN_CORESIDE_KIB") ? std::atoi(std::getenv("HISPMV_PLAN_CORESIDE_KIB")) : 0;
+    if (coreside_kib > 0 && have && have_small && chosen.threads == 1024 && chosen_avg_window * 4.0 <= coreside_kib * 1024.0) { chosen = small; chosen_G = small_G; }
     if (!have) {   // scattered columns: plain L2 gathers, small workgroups
         best.block_threads = 256; best.group_slices = (n / 8 < 1024) ? 4 : 8; best.lds_floats = 0; best.per_cu = 4;
         const int64_t ng = (n + best.group_slices - 1) / best.group_slices;

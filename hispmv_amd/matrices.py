@@ -307,6 +307,69 @@ def coo_to_csr_sorted(r, c, v, rows: int):
     return np.cumsum(rp).astype(np.int32), np.asarray(c, np.int32)[order], np.asarray(v, np.float32)[order]
 
 
+STANDIN_VARIANTS = ("base", "half_band", "double_band", "stray2", "stray5", "stray10", "shuffle4k")
+
+
+def _resort_rows(rp, ci, va):
+    """Columns ascending inside every row again (after columns were rewritten); duplicates are kept."""
+    rows = rp.size - 1
+    row_of = np.repeat(np.arange(rows, dtype=np.int64), np.diff(rp).astype(np.int64))
+    order = np.lexsort((ci, row_of))
+    return rp, ci[order], va[order]
+
+
+def standin_variant(name: str, variant: str):
+    """One of the eight mesh-origin (fem) stand-ins under a perturbation -- where does the launch planner fall off a cliff
+    between the structured family and the pessimistic one?  (tools/standin_sweep.py)
+      base                      the structured stand-in itself
+      half_band / double_band   the stencil's half bandwidth x 0.5 / x 2
+      stray2 / stray5 / stray10 that share of the entries re-drawn with uniform random columns (long-range couplings)
+      shuffle4k                 symmetric permutation of 4096-row blocks (P A P^T: a mesh numbered block by block in random order)
+    -> (rows, cols, row_ptr, col_idx, values)."""
+    entry = next(q for q in SUITESPARSE_SET if q[0] == name)
+    _, rows, nnz, fam, par = entry
+    if fam != "fem":
+        raise ValueError(f"{name} is not one of the mesh-origin stand-ins")
+    seed = zlib.crc32(name.encode())
+    d, run, half = par
+    if variant == "half_band":
+        half = max(run + 1, half // 2)
+    elif variant == "double_band":
+        half = min(half * 2, max(run + 1, (-(-rows // d)) - 1))
+    rp, ci, va = synth_fem(rows, nnz, d, run, half, seed)
+    if variant.startswith("stray"):
+        share = int(variant[5:]) / 100.0
+        rng = np.random.default_rng(seed + 17)
+        pick = rng.random(ci.size) < share
+        ci = ci.copy()
+        ci[pick] = rng.integers(0, rows, size=int(pick.sum()), dtype=np.int64).astype(np.int32)
+        rp, ci, va = _resort_rows(rp, ci, va)
+    elif variant == "shuffle4k":
+        rng = np.random.default_rng(seed + 29)
+        blk = 4096
+        nb = -(-rows // blk)
+        perm_blocks = rng.permutation(nb)
+        # new index of old row i: blocks keep their inner order, the (short) last block stays last so that sizes line up
+        sizes = np.minimum(blk, rows - np.arange(nb) * blk)
+        order = perm_blocks[np.argsort(perm_blocks == nb - 1, kind="stable")] if sizes[-1] != blk else perm_blocks
+        new_start = np.zeros(nb, dtype=np.int64)
+        new_start[order] = np.concatenate([[0], np.cumsum(sizes[order])[:-1]])
+        old = np.arange(rows, dtype=np.int64)
+        new_of_old = new_start[old // blk] + old % blk
+        old_of_new = np.empty(rows, dtype=np.int64)
+        old_of_new[new_of_old] = old
+        lens = np.diff(rp).astype(np.int64)
+        new_lens = lens[old_of_new]
+        nrp = np.concatenate([[0], np.cumsum(new_lens)])
+        src = np.repeat(rp[:-1].astype(np.int64)[old_of_new], new_lens) + (np.arange(int(nrp[-1]), dtype=np.int64) - np.repeat(nrp[:-1], new_lens))
+        ci = new_of_old[ci[src]].astype(np.int32)
+        va = va[src]
+        rp, ci, va = _resort_rows(nrp.astype(np.int32), ci, va)
+    elif variant not in ("base", "half_band", "double_band"):
+        raise ValueError(variant)
+    return rows, rows, rp, ci, va
+
+
 def benchmark_set(names=None, uniform: bool = False, seed_shift: int = 0):
     """The matrices of a bench step (BASELINE.json configs[1]), exactly as bench.py and the parity tests build them:
     a real file under matrices/<name>/ when present, else the seeded stand-in.  -> list of dicts with

@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOT REPRODUCIBLE AT HEAD: the library no longer reads HISPMV_TTS_AUX (the code of this variant was removed after the measurement recorded in
+# profiles/r3_experiments/tts_soc_pokec.json).  Kept as the record of what was run; refuses to run so that it cannot silently measure the default.
+echo "$0: HISPMV_TTS_AUX is not read by libhispmv.so any more -- this experiment is not reproducible at HEAD (see profiles/r3_experiments/)" >&2; exit 2
 # round 3: cache policy of the tile stream's x gathers (buffer_load aux bits: 1 = sc0, 2 = nt, 16 = sc1) on soc-Pokec
 set -e
 out=gpurun_out/r3a; mkdir -p $out

@@ -1,14 +1,16 @@
 // xsweep_lab.hip -- prototype (not product code) of the round-4 format for scattered matrices: the X-SWEEP TILE.
-//   tile        = a range of rows x one column part; one 16-wavefront workgroup
+//   tile        = a range of rows x one column part; one workgroup of NWAVES consumer + 4 producer wavefronts, one per CU
 //   accumulators: one fp32 slot in LDS per pseudo-row (a row of the tile, or one of the k interleaved pieces of a long row);
-//                 a slot belongs to ONE wavefront (slot q -> wavefront q mod 16), so it is updated with plain read-add-write
-//   x           : the tile's column range is swept in windows of W floats, staged into a ring of three LDS buffers with
-//                 coalesced 16-byte loads (every line of x once per tile); step k works on windows k and k+1 while k+2 loads
-//   stream      : per wavefront a sequence of 64-element "instructions" {fp32 value, ring index:16 | slot:16}; the packer
-//                 schedules the elements so that no two lanes of an instruction update the same slot and an instruction of
-//                 step k only touches windows k and k+1
+//                 a slot belongs to ONE consumer wavefront (slot q -> wavefront q mod NWAVES): plain read-add-write, no atomics
+//   x           : the tile's column range is swept in windows of W floats through a ring of RING LDS buffers, staged by the
+//                 producer wavefronts with coalesced 16-byte loads (every line of x once per tile)
+//   stream      : per consumer wavefront a sequence of 64-element instructions {fp32 value, ring index:16 | slot:16} + a header
+//                 {lo, hi} = the windows it touches (hi - lo <= SPAN); the packer schedules the elements so that no two lanes
+//                 of an instruction update the same slot
+//   sync        : no barrier inside the sweep -- ready[p] (windows producer p has written), done[w] (windows consumer w no
+//                 longer needs) in LDS; a consumer waits for ready > hi, a producer for done >= j - RING + 1 before it overwrites
 // Measures the kernel on a soc-Pokec-like matrix (bounded power-law row lengths, uniform columns) and checks y.
-// Build: hipcc --offload-arch=gfx950 -O3 -fopenmp tools/xsweep_lab.hip -o tools/xsweep_lab
+// Build: hipcc --offload-arch=gfx950 -O3 -fopenmp -ffp-contract=off -DNWAVES=12 -DRING=8 tools/xsweep_lab.hip -o tools/xsweep_lab
 #include <hip/hip_runtime.h>
 #include <omp.h>
 
@@ -24,53 +26,57 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 #ifndef NWAVES
-#define NWAVES 8
+#define NWAVES 12
 #endif
-constexpr int kWaves = NWAVES;
-constexpr int kThreads = kWaves * 64;
-static int kPiece = 32;          // elements per piece of a long row (set from the number of windows: <= 1/4 element per piece and window)
+#ifndef RING
+#define RING 8
+#endif
+#ifndef PREFETCH
+#define PREFETCH 4
+#endif
+constexpr int kWaves = NWAVES;                      // consumer wavefronts
+constexpr int kProducers = 4;                       // wavefronts that only stage x windows
+constexpr int kAllThreads = (kWaves + kProducers) * 64;
+constexpr int kSpan = RING - 2;                     // an instruction touches windows lo .. hi, hi - lo <= kSpan
+static int kPiece = 32;                             // elements per piece of a long row
 
 struct Tile {
     int32_t row0, n_rows;           // rows [row0, row0 + n_rows)
     int32_t col0, n_steps;          // first column of the part (multiple of W), windows to sweep
     int32_t n_slots, slots_per_wave;
-    int32_t part, pad;
-    int64_t instr_begin[kWaves];    // first instruction of every wavefront's stream (units of 64 elements)
-    int64_t cnt_begin;              // counts table: n_steps x 16 bytes
+    int32_t part, n_instr;          // instructions of the tile (all wavefronts)
+    int64_t instr_begin[kWaves + 1];    // first instruction of every wavefront's stream (units of 64 elements); [kWaves] = end
     int64_t qb_begin;               // slot offsets of the rows: n_rows + 1 ints
 };
 
-constexpr int kProducers = 4;                      // wavefronts that only stage x windows
-constexpr int kAllThreads = (kWaves + kProducers) * 64;
-
-// Consumers (wavefronts 0 .. kWaves-1) run the element stream, producers (the last kProducers wavefronts) stage the x windows:
-// a consumer's vector-memory queue then holds nothing but its stream prefetches (a statically unrolled ring, unconditional
-// loads: hipcc counts them exactly), a producer's nothing but window loads.  One barrier per step:
-//   producer, step k: window k+1 (registers, loaded during step k-1) -> ring[(k+1) % 3]; request window k+2; barrier B_k
-//   consumer, step k: barrier B_k; its instructions of step k (they touch windows k and k+1 only)
 template <int W>
 __global__ __launch_bounds__(kAllThreads) void xsweep_kernel(const Tile* __restrict__ tiles, const uint2* __restrict__ stream,
-                                                      const uint8_t* __restrict__ counts, const int32_t* __restrict__ qb,
-                                                      const float* __restrict__ x, int cols, float* __restrict__ ypart, int rows) {
+                                                      const uint32_t* __restrict__ hdrs, const int32_t* __restrict__ qb,
+                                                      const float* __restrict__ x, int cols, float* __restrict__ ypart, int rows, int mode) {
+    // mode 0: the kernel; 1: producers only (consumers declare every window free at once); 2: consumers only (producers declare every
+    // window written without loading it): the floors of the two sides
     extern __shared__ float lds[];
-    float* const win = lds;                 // 3 * W
-    float* const acc = lds + 3 * W;         // kWaves * slots_per_wave + 64
+    float* const win = lds;                 // RING * W
+    float* const acc = lds + RING * W;      // kWaves * slots_per_wave + 64
     const Tile& T = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_steps = T.n_steps;
     const int acc_n = T.slots_per_wave * kWaves + 64;
-    uint8_t* const cnt = (uint8_t*)(acc + acc_n);          // n_steps * kWaves bytes
+    volatile int* const flags = (volatile int*)(acc + acc_n);        // ready[4], done[16]
+    uint32_t* const hdr = (uint32_t*)(acc + acc_n + 32);             // one per instruction of the tile: lo | hi << 16
     for (int i = threadIdx.x; i < acc_n; i += kAllThreads) acc[i] = 0.0f;
-    for (int i = threadIdx.x; i < n_steps * kWaves; i += kAllThreads) cnt[i] = counts[T.cnt_begin + i];
+    for (int i = threadIdx.x; i < T.n_instr; i += kAllThreads) hdr[i] = hdrs[T.instr_begin[0] + i];
+    if (threadIdx.x < 32) flags[threadIdx.x] = threadIdx.x >= 4 + kWaves && threadIdx.x < 20 ? 0x7fffffff : 0;      // (unused done[] entries never hold a producer back)
+    __syncthreads();
     if (wave >= kWaves) {
         // ---------------- producer
+        const int pw = wave - kWaves;
+        if (mode == 2) { if (lane == 0) flags[pw] = 0x7ffffff0; }
+        else {
         const int pt = threadIdx.x - kWaves * 64;            // 0 .. kProducers*64-1
         constexpr int kQ = W / (kProducers * 64 * 4);        // float4 per thread and window
-#ifndef PREFETCH
-#define PREFETCH 3
-#endif
-        constexpr int PD = PREFETCH;                             // windows in flight (registers) ahead of the one being written
+        constexpr int PD = PREFETCH;                         // windows in flight (registers)
         float4 r[PD][kQ];
         auto load_win = [&](int k, float4* nxt) {
 #pragma unroll
@@ -80,44 +86,61 @@ __global__ __launch_bounds__(kAllThreads) void xsweep_kernel(const Tile* __restr
             }
         };
         auto store_win = [&](int k, const float4* nxt) {
-            float* b = win + (k % 3) * W;
+            float* b = win + (k % RING) * W;
 #pragma unroll
             for (int q = 0; q < kQ; ++q) *(float4*)(b + q * (kProducers * 256) + pt * 4) = nxt[q];
         };
-        load_win(0, r[0]); store_win(0, r[0]);
 #pragma unroll
-        for (int j = 0; j < PD; ++j) load_win(j + 1, r[j]);      // r[j] holds window j + 1
-        for (int k = 0; k < n_steps; k += PD) {
+        for (int j = 0; j < PD; ++j) load_win(j, r[j]);          // r[j] holds window j
+        int freed = 0;                                           // windows below this are no longer needed by any consumer
+        for (int j0 = 0; j0 < n_steps; j0 += PD) {
 #pragma unroll
-            for (int j = 0; j < PD; ++j) {
-                if (k + j < n_steps) {
-                    store_win(k + j + 1, r[j]);                  // requested PD steps ago
-                    load_win(k + j + 1 + PD, r[j]);
-                    __syncthreads();
+            for (int u = 0; u < PD; ++u) {
+                const int j = j0 + u;
+                if (j < n_steps) {
+                    while (freed < j - RING + 1) {
+                        int m = 0x7fffffff;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) m = min(m, flags[4 + q]);
+                        freed = __builtin_amdgcn_readfirstlane(m);
+                        if (freed < j - RING + 1) __builtin_amdgcn_s_sleep(2);
+                    }
+                    store_win(j, r[u]);
+                    load_win(j + PD, r[u]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) flags[pw] = j + 1;
                 }
             }
         }
+        }
     } else {
         // ---------------- consumer
+        if (mode == 1) { if (lane == 0) flags[4 + wave] = 0x7fffffff; }
+        else {
+        const int i0 = (int)(T.instr_begin[wave] - T.instr_begin[0]);
+        const int total = (int)(T.instr_begin[wave + 1] - T.instr_begin[wave]);          // a multiple of D
         const uint2* sp = stream + (size_t)T.instr_begin[wave] * 64 + lane;
-        int total = 0;
-        __syncthreads();                                      // B_0: counts, accumulators, windows 0 and 1 are in the LDS
-        for (int k = 0; k < n_steps; ++k) total += cnt[k * kWaves + wave];
-        total = __builtin_amdgcn_readfirstlane(total);
-        // The stream ring: D instructions in flight per wavefront, loads issued with inline asm and awaited with an explicit
-        // s_waitcnt vmcnt(D-1): hipcc's own wait insertion drains the queue once per trip of a loop like this one (vmcnt(1)
-        // before the oldest buffer), which exposes an HBM latency every D instructions -- and with one barrier per step the
-        // whole workgroup then runs at the pace of whichever wavefront is draining.
         constexpr int D = 8;
         unsigned long long buf[D];
         auto issue = [&](unsigned long long& dst, const uint2* ptr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
 #pragma unroll
         for (int u = 0; u < D; ++u) issue(buf[u], sp + (size_t)u * 64);           // (the stream has D instructions of slack behind its end)
-        int k = 0, remaining = __builtin_amdgcn_readfirstlane((int)cnt[wave]);
+        int seen = 0, published = 0;
         for (int pos = 0; pos < total; pos += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                if (remaining == 0) { ++k; __syncthreads(); remaining = __builtin_amdgcn_readfirstlane((int)cnt[k * kWaves + wave]); }
+                const unsigned h = __builtin_amdgcn_readfirstlane(hdr[i0 + pos + u]);
+                const int lo = (int)(h & 0xffffu), hi = (int)(h >> 16);
+                if (lo > published) {                            // windows below lo are free
+                    published = lo;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) flags[4 + wave] = lo;
+                }
+                while (seen <= hi) {                             // window hi must have been written by all producers
+                    seen = __builtin_amdgcn_readfirstlane(min(min(flags[0], flags[1]), min(flags[2], flags[3])));
+                    if (seen <= hi) __builtin_amdgcn_s_sleep(1);
+                    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
                 asm volatile("s_waitcnt vmcnt(7)" : "+v"(buf[u]) :: "memory");
                 const unsigned ev = (unsigned)buf[u], em = (unsigned)(buf[u] >> 32);
                 const float xv = win[em & 0xffffu];
@@ -125,12 +148,13 @@ __global__ __launch_bounds__(kAllThreads) void xsweep_kernel(const Tile* __restr
                 const float p = __builtin_bit_cast(float, ev) * xv;
                 const float a = acc[slot];
                 acc[slot] = a + p;
-                --remaining;
                 issue(buf[u], sp + (size_t)(pos + u + D) * 64);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]) :: "memory");
-        while (k < n_steps - 1) { ++k; __syncthreads(); }   // every wavefront passes the same number of barriers
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) flags[4 + wave] = 0x7fffffff;                 // done with every window
+        }
     }
     __syncthreads();
     // rows of the tile: the pieces of a row are consecutive slots q; slot q lives at (q % kWaves) * S + q / kWaves
@@ -146,7 +170,7 @@ __global__ __launch_bounds__(kAllThreads) void xsweep_kernel(const Tile* __restr
 }
 
 int main(int argc, char** argv) {
-    int rows = 1632803, W = 8192, parts = 2, tile_slots = 12288;
+    int rows = 1632803, W = 3072, parts = 2, tile_slots = 0;
     double avg = 18.75;
     if (argc > 1) W = atoi(argv[1]);
     if (argc > 2) parts = atoi(argv[2]);
@@ -183,10 +207,10 @@ int main(int argc, char** argv) {
     std::vector<float> x((size_t)cols + 4);
     for (int j = 0; j < cols; ++j) x[j] = (float)((j % 1000) / 1000.0 + 0.001);
 
-    // --- tiles: column parts of equal width (multiple of W); row ranges with <= tile_slots slots and ~ equal elements
+    // --- tiles: column parts of equal width (multiple of W); exactly n_cus tiles
     const int part_w = (int)((((int64_t)cols + parts - 1) / parts + W - 1) / W * W);
     kPiece = std::max(4, std::min(32, part_w / W / 4));
-    printf("piece = %d elements\n", kPiece);
+    printf("piece = %d elements, span = %d windows\n", kPiece, kSpan);
     std::vector<Tile> tiles;
     const int n_cus = 256;
     const int row_tiles_wanted = std::max(1, n_cus / parts);
@@ -213,7 +237,7 @@ int main(int argc, char** argv) {
     const int n_tiles = (int)tiles.size();
     printf("%d tiles (%d row ranges)\n", n_tiles, n_tiles / parts);
     // --- pack every tile
-    struct Packed { std::vector<uint2> instr[kWaves]; std::vector<uint8_t> counts; std::vector<int32_t> qb; int64_t pad = 0, elems = 0; };
+    struct Packed { std::vector<uint2> instr[kWaves]; std::vector<uint32_t> hdr[kWaves]; std::vector<int32_t> qb; int64_t pad = 0, elems = 0; };
     std::vector<Packed> packed((size_t)n_tiles);
     double t0 = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 1)
@@ -241,112 +265,83 @@ int main(int argc, char** argv) {
         }
         P.qb[T.n_rows] = q;
         T.n_slots = q; T.slots_per_wave = (q + kWaves - 1) / kWaves;
-        P.counts.assign((size_t)T.n_steps * kWaves, 0);
+        const int S = T.slots_per_wave;
         for (int w = 0; w < kWaves; ++w) {
             auto& E = we[w];
             std::stable_sort(E.begin(), E.end(), [](const El& a, const El& b2) { return a.win < b2.win; });
-            const int S = T.slots_per_wave;
-            // step k may use windows k (last chance) and k + 1.  The mandatory elements open as many instructions as they need
-            // (no two lanes of an instruction on the same slot), the optional ones fill them; further instructions only full ones.
-            std::vector<El> M, O, rest;
-            size_t next = 0;
-            auto emit = [&](std::vector<El>& ins, int k) {
+            P.elems += (int64_t)E.size();
+            // greedy: an instruction takes the oldest unscheduled elements, at most 64, windows within first .. first + kSpan,
+            // no slot twice (an element whose slot is taken stays for the next instruction)
+            std::vector<char> taken(E.size(), 0);
+            std::vector<int32_t> mark((size_t)S, -1);
+            size_t head = 0; int ino = 0;
+            auto emit = [&](const std::vector<size_t>& pick, int lo, int hi) {
                 for (size_t l = 0; l < 64; ++l) {
-                    if (l < ins.size()) {
-                        const El& e = ins[l];
-                        const uint32_t ring = (uint32_t)((e.win % 3) * W + (e.col - c0) % W);
+                    if (l < pick.size()) {
+                        const El& e = E[pick[l]];
+                        const uint32_t ring = (uint32_t)((e.win % RING) * W + (e.col - c0) % W);
                         const uint32_t slot = (uint32_t)(w * S + e.q / kWaves);
                         uint32_t vb; memcpy(&vb, &e.v, 4);
                         P.instr[w].push_back(uint2{vb, ring | (slot << 16)});
                     } else { P.instr[w].push_back(uint2{0u, (uint32_t)(kWaves * S + l) << 16}); P.pad++; }
                 }
-                if (++P.counts[(size_t)k * kWaves + w] == 255) { fprintf(stderr, "count overflow\n"); exit(1); }
+                P.hdr[w].push_back((uint32_t)lo | ((uint32_t)hi << 16));
             };
-            for (int k = 0; k < T.n_steps; ++k) {
-                M.swap(O); O.clear();                  // what was optional is mandatory now
-                if (k == 0) { while (next < E.size() && E[next].win <= 0) M.push_back(E[next++]); }
-                while (next < E.size() && E[next].win <= k + 1) O.push_back(E[next++]);
-                std::vector<std::vector<El>> ins;
-                auto place = [&](const El& e) {
-                    for (auto& I : ins) {
-                        if (I.size() >= 64) continue;
-                        bool clash = false;
-                        for (const El& o : I) if (o.q == e.q) { clash = true; break; }
-                        if (!clash) { I.push_back(e); return true; }
-                    }
-                    return false;
-                };
-                for (const El& e : M) if (!place(e)) { ins.emplace_back(); ins.back().push_back(e); }
-                rest.clear();
-                for (const El& e : O) if (!place(e)) rest.push_back(e);
-                while (rest.size() >= 64) {               // more full instructions from the optional elements
-                    std::vector<El> I, left;
-                    for (const El& e : rest) {
-                        bool clash = I.size() >= 64;
-                        for (size_t z = 0; !clash && z < I.size(); ++z) clash = I[z].q == e.q;
-                        if (clash) left.push_back(e); else I.push_back(e);
-                    }
-                    if (I.size() < 64) break;
-                    ins.push_back(std::move(I)); rest.swap(left);
+            int last_lo = 0;
+            while (head < E.size()) {
+                while (head < E.size() && taken[head]) ++head;
+                if (head >= E.size()) break;
+                const int lo = E[head].win;
+                std::vector<size_t> pick;
+                int hi = lo;
+                for (size_t z = head; z < E.size() && pick.size() < 64 && E[z].win <= lo + kSpan; ++z) {
+                    if (taken[z]) continue;
+                    const int ls = E[z].q / kWaves;
+                    if (mark[ls] == ino) continue;
+                    mark[ls] = ino; taken[z] = 1; pick.push_back(z); hi = std::max(hi, (int)E[z].win);
                 }
-                O = rest;
-                if (ins.empty()) ins.emplace_back();     // every wavefront has >= 1 instruction in every step: the consumer passes ONE barrier per step change
-                for (auto& I : ins) emit(I, k);
-                P.elems += 0;
+                emit(pick, lo, hi); ++ino; last_lo = lo;
             }
-            while ((P.instr[w].size() / 64) % 8 != 0) {      // whole groups of D = 8 instructions: the consumer loop has no remainder branch
-                std::vector<El> none; emit(none, T.n_steps - 1);
-            }
-            P.elems += (int64_t)E.size();
-            if (false && t == 5 && w < 3) { fprintf(stderr, "tile 5 wave %d: %zu elements, %zu instr; steps:", w, E.size(), P.instr[w].size() / 64); for (int k = 0; k < T.n_steps; ++k) { int c = 0; for (auto& e : E) c += e.win == k; fprintf(stderr, " %d/%d", c, (int)P.counts[(size_t)k * kWaves + w]); } fprintf(stderr, "\n"); }
-            if (!O.empty()) { fprintf(stderr, "elements left over\n"); exit(1); }
+            while ((P.instr[w].size() / 64) % 8 != 0) { std::vector<size_t> none; emit(none, last_lo, last_lo); }     // whole groups of D = 8 instructions
         }
     }
     printf("packed in %.1f s\n", omp_get_wtime() - t0);
     // --- concatenate
-    std::vector<uint2> stream; std::vector<uint8_t> counts; std::vector<int32_t> qb;
-    int64_t pad = 0, elems = 0; int max_spw = 0, max_steps = 0;
+    std::vector<uint2> stream; std::vector<uint32_t> hdrs; std::vector<int32_t> qb;
+    int64_t pad = 0, elems = 0; int max_spw = 0, max_steps = 0, max_instr = 0;
     for (int t = 0; t < n_tiles; ++t) {
         Tile& T = tiles[t]; Packed& P = packed[t];
-        for (int w = 0; w < kWaves; ++w) { T.instr_begin[w] = (int64_t)stream.size() / 64; stream.insert(stream.end(), P.instr[w].begin(), P.instr[w].end()); }
-        T.cnt_begin = (int64_t)counts.size(); counts.insert(counts.end(), P.counts.begin(), P.counts.end());
+        for (int w = 0; w < kWaves; ++w) {
+            T.instr_begin[w] = (int64_t)stream.size() / 64;
+            stream.insert(stream.end(), P.instr[w].begin(), P.instr[w].end());
+            hdrs.insert(hdrs.end(), P.hdr[w].begin(), P.hdr[w].end());
+        }
+        T.instr_begin[kWaves] = (int64_t)stream.size() / 64;
+        T.n_instr = (int)(T.instr_begin[kWaves] - T.instr_begin[0]);
         T.qb_begin = (int64_t)qb.size(); qb.insert(qb.end(), P.qb.begin(), P.qb.end());
-        pad += P.pad; elems += P.elems; max_spw = std::max(max_spw, T.slots_per_wave); max_steps = std::max(max_steps, T.n_steps);
+        pad += P.pad; elems += P.elems; max_spw = std::max(max_spw, T.slots_per_wave); max_steps = std::max(max_steps, T.n_steps); max_instr = std::max(max_instr, T.n_instr);
     }
-    printf("stream %.1f MB (%lld elements + %lld padding = %.2f %%), counts %.2f MB, qb %.1f MB, max slots per wave %d, steps %d\n", stream.size() * 8 / 1e6,
-           (long long)elems, (long long)pad, 100.0 * pad / std::max<int64_t>(1, elems), counts.size() / 1e6, qb.size() * 4 / 1e6, max_spw, max_steps);
-    const size_t lds = ((size_t)3 * W + (size_t)max_spw * kWaves + 64) * 4 + (size_t)max_steps * kWaves + 64;
+    printf("stream %.1f MB (%lld elements + %lld padding = %.2f %%), headers %.2f MB, qb %.1f MB, max slots per wave %d, steps %d, max instructions per tile %d\n", stream.size() * 8 / 1e6,
+           (long long)elems, (long long)pad, 100.0 * pad / std::max<int64_t>(1, elems), hdrs.size() * 4 / 1e6, qb.size() * 4 / 1e6, max_spw, max_steps, max_instr);
+    const size_t lds = ((size_t)RING * W + (size_t)max_spw * kWaves + 64 + 32 + (size_t)max_instr) * 4 + 64;
     printf("LDS per workgroup %.1f KiB\n", lds / 1024.0);
     if (lds > 160 * 1024 - 256) { printf("does not fit\n"); return 1; }
-    // longest tiles first
-    std::vector<int> order((size_t)n_tiles);
-    for (int i = 0; i < n_tiles; ++i) order[i] = i;
-    std::vector<int64_t> work((size_t)n_tiles);
-    for (int t = 0; t < n_tiles; ++t) { work[t] = 0; for (int w = 0; w < kWaves; ++w) work[t] = std::max<int64_t>(work[t], (int64_t)packed[t].instr[w].size()); }
-    // (256 tiles on 256 CUs: all resident at once; the order IS the XCD mapping)
-    std::vector<Tile> sorted;
-    for (int i : order) sorted.push_back(tiles[i]);
 
-    Tile* d_tiles; uint2* d_stream; uint8_t* d_counts; int32_t* d_qb; float *d_x, *d_y;
-    CK(hipMalloc(&d_tiles, sorted.size() * sizeof(Tile))); CK(hipMemcpy(d_tiles, sorted.data(), sorted.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    Tile* d_tiles; uint2* d_stream; uint32_t* d_hdrs; int32_t* d_qb; float *d_x, *d_y;
+    CK(hipMalloc(&d_tiles, tiles.size() * sizeof(Tile))); CK(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_stream, stream.size() * 8 + 64 * 512)); CK(hipMemcpy(d_stream, stream.data(), stream.size() * 8, hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_counts, counts.size() + 64)); CK(hipMemcpy(d_counts, counts.data(), counts.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_hdrs, hdrs.size() * 4 + 64)); CK(hipMemcpy(d_hdrs, hdrs.data(), hdrs.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_qb, qb.size() * 4)); CK(hipMemcpy(d_qb, qb.data(), qb.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_x, x.size() * 4)); CK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_y, (size_t)parts * rows * 4)); CK(hipMemset(d_y, 0xff, (size_t)parts * rows * 4));
+#define LAUNCH(WW) hipLaunchKernelGGL(xsweep_kernel<WW>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_hdrs, d_qb, d_x, cols, d_y, rows, mode)
+    int mode = 0;
     auto launch = [&]() {
-        if (W == 4096) hipLaunchKernelGGL(xsweep_kernel<4096>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
-        else if (W == 8192) hipLaunchKernelGGL(xsweep_kernel<8192>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
-        else if (W == 3072) hipLaunchKernelGGL(xsweep_kernel<3072>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
-        else if (W == 6144) hipLaunchKernelGGL(xsweep_kernel<6144>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
-        else if (W == 12288) hipLaunchKernelGGL(xsweep_kernel<12288>, dim3(n_tiles), dim3(kAllThreads), lds, 0, d_tiles, d_stream, d_counts, d_qb, d_x, cols, d_y, rows);
-        else { printf("unsupported W\n"); exit(1); }
+        if (W == 1024) LAUNCH(1024); else if (W == 2048) LAUNCH(2048); else if (W == 3072) LAUNCH(3072); else if (W == 4096) LAUNCH(4096);
+        else if (W == 6144) LAUNCH(6144); else if (W == 8192) LAUNCH(8192); else { printf("unsupported W\n"); exit(1); }
     };
-    CK(hipFuncSetAttribute((const void*)xsweep_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    CK(hipFuncSetAttribute((const void*)xsweep_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    CK(hipFuncSetAttribute((const void*)xsweep_kernel<3072>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    CK(hipFuncSetAttribute((const void*)xsweep_kernel<6144>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    CK(hipFuncSetAttribute((const void*)xsweep_kernel<12288>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+#define RAISE(WW) CK(hipFuncSetAttribute((const void*)xsweep_kernel<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
+    RAISE(1024); RAISE(2048); RAISE(3072); RAISE(4096); RAISE(6144); RAISE(8192);
     launch(); CK(hipDeviceSynchronize());
     // --- check
     std::vector<float> y((size_t)parts * rows);
@@ -363,14 +358,15 @@ int main(int argc, char** argv) {
     }
     printf("check: worst backward error %.3g, %d bad rows\n", worst, bad);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int md : {0, 0, 1, 2}) {
+        mode = md;
         for (int i = 0; i < 5; ++i) launch();
         CK(hipEventRecord(e0));
         const int reps = 20;
         for (int i = 0; i < reps; ++i) launch();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("kernel %.1f us  (%.1f Gelem/s, algorithmic %.0f GB/s)\n", ms * 1e3, nnz / ms / 1e6, (8.0 * nnz + 16.0 * rows) / ms / 1e6);
+        printf("%s %.1f us  (%.1f Gelem/s, algorithmic %.0f GB/s)\n", md == 0 ? "kernel" : md == 1 ? "producers only" : "consumers only", ms * 1e3, nnz / ms / 1e6, (8.0 * nnz + 16.0 * rows) / ms / 1e6);
     }
     return bad != 0;
 }
