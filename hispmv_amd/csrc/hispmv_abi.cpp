@@ -290,7 +290,21 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
     if (const char* env = std::getenv("HISPMV_BATCH_ORDER")) c->batch_order = !std::strcmp(env, "small_first") ? 1 : 0;
     if (const char* env = std::getenv("HISPMV_BATCH_LANES")) c->batch_lanes_heavy_first = std::strcmp(env, "rr") != 0;
     if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) { c->batch_streams = std::max(1, std::min(3, std::atoi(env))); c->batch_streams_min_bytes = 0; }
+    // Experiment (HISPMV_CU_SPLIT=<hexA>:<hexB>, round 4): the two side streams get CU masks (the 32-bit pattern repeated over the
+    // device's CUs) and a batch call sends its slice / dense grids to side stream 0 and its tile-stream grids to side stream 1 --
+    // an HBM-bound grid does not need every CU to saturate the memory, a cache-bound one wants as many as it can get.
+    uint32_t cu_pat[2] = {0, 0};
+    if (const char* env = std::getenv("HISPMV_CU_SPLIT")) {
+        char* end = nullptr;
+        cu_pat[0] = (uint32_t)std::strtoul(env, &end, 16);
+        if (end && *end == ':') cu_pat[1] = (uint32_t)std::strtoul(end + 1, nullptr, 16);
+        c->cu_split = cu_pat[0] != 0 && cu_pat[1] != 0;
+    }
     for (int i = 0; i < 2; ++i) {
+        if (c->cu_split) {
+            std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, cu_pat[i]);
+            if ((e = hipExtStreamCreateWithCUMask(&c->side[i], (uint32_t)mask.size(), mask.data())) != hipSuccess) return give_up(e, "hipExtStreamCreateWithCUMask");
+        } else
         if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return give_up(e, "hipStreamCreate(side)");
         if ((e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)) != hipSuccess) return give_up(e, "hipEventCreate(join)");
     }

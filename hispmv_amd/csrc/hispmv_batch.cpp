@@ -355,7 +355,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     }
     // main launches (kinds 0 and 3) are independent of each other: spread over the caller's stream and the side streams;
     // the fix-up and merge launches follow on the caller's stream behind a join
-    const int lanes = plan->lanes;
+    const int lanes = c->cu_split ? 3 : plan->lanes;
     // the launches, as one function of the stream: main launches spread over the caller's stream and the side streams (forked
     // from / joined to it with events), fix-up and merge behind the join
     auto enqueue = [&]() -> int {
@@ -369,6 +369,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
             const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
             hipStream_t ls = s;
             if (is_main && lanes > 1) ls = l.lane == 0 ? s : c->side[l.lane - 1];
+            if (is_main && c->cu_split) ls = l.kind == 3 ? c->side[1] : c->side[0];
             if (!is_main && !joined) {
                 for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
                 joined = true;
@@ -399,7 +400,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool caller_captures = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
     (void)hipGetLastError();
-    if (c->batch_graphs && lanes > 1 && !caller_captures) {      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
+    if (c->batch_graphs && lanes > 1 && !caller_captures && !c->cu_split) {      // (a graph replay maps its branches to the runtime's own queues: the CU masks would be lost)      // (one-stream calls: a graph launch costs more than their 2-4 plain launches, the model layers 50 -> 54 us)
         using Slot = hispmv_ctx::BatchPlan::GraphSlot;
         auto drop_graphs = [&]() {
             for (Slot& g : plan->slot) {

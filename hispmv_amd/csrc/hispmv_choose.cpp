@@ -12,6 +12,7 @@ FormatOptions FormatOptions::from_env() {
     FormatOptions o;
     if (const char* e = std::getenv("HISPMV_FORMAT")) o.format_mode = !std::strcmp(e, "slices") ? 0 : !std::strcmp(e, "tts") ? 1 : 2;
     if (const char* e = std::getenv("HISPMV_BAND_TILES")) o.band_tiles = std::atoi(e) != 0;
+    if (const char* e = std::getenv("HISPMV_STRAY_SPLIT")) o.stray_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("HISPMV_TTS_GEOMETRY"))
         o.tts_geometry = !std::strcmp(e, "standard") ? 0 : !std::strcmp(e, "tall") ? 1 : !std::strcmp(e, "paired") ? 3 : !std::strcmp(e, "zerofill") ? 4 : 2;
     if (const char* e = std::getenv("HISPMV_COL_TILE_BYTES")) o.col_tile_bytes = std::atoll(e);
@@ -108,6 +109,26 @@ void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p
 
 }  // namespace
 
+std::vector<uint8_t> window_membership(const Csr& csr, const LaunchPlan& plan) {
+    const int64_t G = plan.group_slices;
+    const std::vector<int64_t> eoff = stream_row_offsets(csr.rows, csr.row_ptr.data());
+    std::vector<uint8_t> inside((size_t)csr.nnz());
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 1024)
+    for (int32_t i = 0; i < csr.rows; ++i) {
+        for (int64_t k = csr.row_ptr[i]; k < csr.row_ptr[(size_t)i + 1]; ++k) {
+            const int64_t g = ((eoff[i] + (k - csr.row_ptr[i])) / kSliceElems) / G;
+            if ((size_t)g >= plan.groups.size()) { inside[(size_t)k] = 0; continue; }
+            const GroupDesc& gd = plan.groups[(size_t)g];
+            const Frag* f0 = plan.frags.data() + gd.frag_begin;
+            const Frag* f1 = f0 + gd.frag_count;
+            const int32_t c = csr.col[(size_t)k];
+            const Frag* it = std::upper_bound(f0, f1, c, [](int32_t col, const Frag& f) { return col < f.col_start; });
+            inside[(size_t)k] = it != f0 && c < (it - 1)->col_start + (it - 1)->len;
+        }
+    }
+    return inside;
+}
+
 FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const FormatOptions& opt,
                            const std::function<void(const char*)>& lap_fn) {
     auto lap = [&](const char* what) { if (lap_fn) lap_fn(what); };
@@ -176,6 +197,59 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     // unstructured band, 742 KB of x, is 39.5 us as a tile stream and 45 as a slice stream; the pessimistic family's step
     // 0.329 -> 0.363 ms with that threshold.)
     const bool x_is_small = (int64_t)used * 4 <= (256 << 10);
+    // STRAY SPLIT (round 4; tile_kind 3): the plan has a window, but a few per cent of the elements lie outside it -- long-range
+    // couplings of an otherwise banded / clustered matrix.  One stray element makes its whole GROUP take 8-byte elements and the
+    // two-way gather (window read + predicated gather through L2): with 2 % of the entries re-drawn at random columns EVERY group of
+    // the PFlow_742 stand-in has strays and the matrix falls from 0.70 to 0.43 of the roofline (tools/standin_sweep.py,
+    // profiles/r4_standin_sweep.json).  The matrix is split A = A_in + A_out by exactly that criterion -- an element is "in" when the
+    // window of ITS group (the planner's fragment list) holds its 64-byte block of x: part 0 = A_in keeps the rows, gets clean
+    // windows and 6-byte elements again, part 1 = A_out (the strays) is a small scattered matrix that gathers through L2 and writes
+    // alpha * A_out * x into a partial vector the tail launch adds -- the reference's hybrid row distribution (dense part on the
+    // PEs' own rows, the rest through the shared-row network, spmv-helper.cpp:265-347) in the coordinates of the x window.
+    if (opt.stray_split && opt.format_mode != 1 && whole.lds_floats > 0 && nnz_all >= (1 << 20) &&
+        whole.global_elems * 1000 > all_elems && whole.global_elems * 100 <= 15 * all_elems) {
+        const std::vector<uint8_t> inside = window_membership(csr, out.parts[0].plan);
+        auto take = [&](bool want) {
+            Csr t;
+            t.rows = csr.rows; t.cols = csr.cols;
+            t.row_ptr.assign((size_t)csr.rows + 1, 0);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+            for (int32_t i = 0; i < csr.rows; ++i) {
+                int64_t n = 0;
+                for (int64_t k = csr.row_ptr[i]; k < csr.row_ptr[(size_t)i + 1]; ++k) n += (inside[(size_t)k] != 0) == want;
+                t.row_ptr[(size_t)i + 1] = n;
+            }
+            for (int32_t i = 0; i < csr.rows; ++i) t.row_ptr[(size_t)i + 1] += t.row_ptr[i];
+            t.col.resize((size_t)t.row_ptr[csr.rows]); t.val.resize((size_t)t.row_ptr[csr.rows]);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+            for (int32_t i = 0; i < csr.rows; ++i) {
+                int64_t o = t.row_ptr[i];
+                for (int64_t k = csr.row_ptr[i]; k < csr.row_ptr[(size_t)i + 1]; ++k)
+                    if ((inside[(size_t)k] != 0) == want) { t.col[(size_t)o] = csr.col[(size_t)k]; t.val[(size_t)o] = csr.val[(size_t)k]; ++o; }
+            }
+            return t;
+        };
+        std::vector<HostPart> parts(2);
+        {
+            Csr in = take(true);
+            parts[0].st = build_stream(in);
+            plan_part(parts[0], n_cus);
+        }
+        const HostPart& q = parts[0];
+        // accepted when the band part really comes out clean (<= 0.5 % of its elements outside the windows)
+        if (q.plan.lds_floats > 0 && q.plan.global_elems * 200 <= q.st.n_slices * (int64_t)kSliceElems) {
+            pack_part(parts[0], opt);
+            Csr outp = take(false);
+            parts[1].st = build_stream(outp);
+            finish_part(parts[1], n_cus, opt);
+            lap("stray split");
+            out.parts = std::move(parts);
+            out.tile_kind = 3;
+            csr = Csr{};
+            return out;
+        }
+        lap("stray split (rejected)");
+    }
     // BAND TILES: a banded matrix whose band is wider than an LDS window -- every group of rows touches band + rows columns --
     // is cut along the DIAGONAL: part t holds the elements whose offset from the (scaled) diagonal lies in the t-th of P equal
     // ranges of the band.  A group of a part then touches (band / P + its rows) columns: a window that fits, every element in

@@ -29,6 +29,7 @@ struct FormatOptions {
     int format_mode = 2;          // HISPMV_FORMAT: 0 slices always, 1 tile stream whenever the plan has no window, 2 auto
     int tts_geometry = 0;         // HISPMV_TTS_GEOMETRY: 0 standard, 1 tall, 2 auto, 3 paired, 4 zerofill
     bool band_tiles = true;       // HISPMV_BAND_TILES
+    bool stray_split = true;      // HISPMV_STRAY_SPLIT: the few elements outside the groups' x windows become a second part (tile_kind 3)
     int64_t col_tile_bytes = 4 << 20;   // HISPMV_COL_TILE_BYTES: x bytes per L2-sized column tile (0 = no tiling)
     int64_t tts_min_nnz = 1 << 20;      // HISPMV_TTS_MIN_NNZ
     bool tts_small = false;             // HISPMV_TTS_SMALL (experiment)
@@ -38,12 +39,17 @@ struct FormatOptions {
 
 struct FormatChoice {
     int format = 0;               // 0 slice stream(s), 1 transposed tile stream(s)
-    int tile_kind = 0;            // parts.size() > 1: 1 column ranges, 2 ranges of the offset from the scaled diagonal (band tiles)
+    int tile_kind = 0;            // parts.size() > 1: 1 column ranges, 2 ranges of the offset from the scaled diagonal (band tiles),
+                                  //   3 stray split (part 0: the elements inside their group's x window, part 1: the others)
     int col_tile_width = 0, col_tile_base = 0;
     bool l2_tiles = false;        // the column tiles gather x through L2: pinned to XCD subsets in a batch call
     double tts_lines_per_gather = 0;
     std::vector<HostPart> parts;
 };
+
+// For every CSR entry: 1 when the x window of ITS workgroup in `plan` (the launch plan of the matrix's whole slice stream) holds
+// the entry's 64-byte block of x, 0 when the entry gathers through L2 -- the criterion of the stray split.
+std::vector<uint8_t> window_membership(const Csr& csr, const LaunchPlan& plan);
 
 // Decides the device format of `csr` for a device with n_cus compute units and builds its parts.  `prebuilt` (may be NULL):
 // the whole-matrix slice stream when the device preprocessor has already made it.  `lap` (may be empty) is called with the

@@ -78,6 +78,7 @@ struct hispmv_ctx {
     // stream and to these side streams, forked from / joined to it with events, so that the tail of one grid overlaps the
     // head of the next (HISPMV_BATCH_STREAMS=1 keeps everything on one stream)
     hipStream_t side[2] = {nullptr, nullptr};
+    bool cu_split = false;       // HISPMV_CU_SPLIT (experiment): the side streams carry CU masks; slice / dense grids -> side[0], tile streams -> side[1]
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int batch_streams = 2;
     int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first

@@ -24,6 +24,10 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef HISPMV_TTS_EXPERIMENT
+#define HISPMV_TTS_EXPERIMENT 0
+#endif
+
 namespace hispmv {
 
 // ---------------------------------------------------------------------------
@@ -821,14 +825,14 @@ __device__ __forceinline__ void batched_group(
             val[4 * j + 2] = i2f((int)w.v[j].z); val[4 * j + 3] = i2f((int)w.v[j].w);
         }
         int r0[kSliceSteps];
-        bool ends[kE];
+        unsigned long long em[kE];           // row-end masks of the slice's 16 element positions (wave-uniform)
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             int below = 0, total = 0;
 #pragma unroll
             for (int k = 0; k < kLaneElems; ++k) {
-                ends[4 * j + k] = (c[4 * j + k] & kRowEndBit) != 0;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(ends[4 * j + k]);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64((c[4 * j + k] & kRowEndBit) != 0);
+                em[4 * j + k] = m;
                 below += lanes_below(m);
                 total += __builtin_popcountll(m);
             }
@@ -878,11 +882,23 @@ __device__ __forceinline__ void batched_group(
             }
             float t[kE];
             float carry_step = 0.0f;
+            // The row-end masks are the same for every vector, and hipcc hoisted everything derived from them -- the 4 x 7 scan flag
+            // words of scan_flags() -- out of the unrolled vector loop: 56 more scalar registers live across it than the SGPR
+            // file has, 179 spilled SGPRs and ~740 v_readlane reloads per slice inside the loop (tools/spill_report.py).  Each
+            // vector therefore takes its masks through an opaque copy: the flag words are recomputed per vector on the scalar
+            // unit (40 SALU instructions per step) and die with it.
+            bool ev[kE];
+#pragma unroll
+            for (int i = 0; i < kE; ++i) {
+                unsigned long long m = em[i];
+                asm volatile("" : "+s"(m));
+                ev[i] = __builtin_amdgcn_inverse_ballot_w64(m);
+            }
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
                 const float pj[kLaneElems] = {val[4 * j] * xg[4 * j], val[4 * j + 1] * xg[4 * j + 1], val[4 * j + 2] * xg[4 * j + 2], val[4 * j + 3] * xg[4 * j + 3]};
                 float tj[kLaneElems];
-                scan_step(pj, ends[4 * j], ends[4 * j + 1], ends[4 * j + 2], ends[4 * j + 3], carry_step, tj);
+                scan_step(pj, ev[4 * j], ev[4 * j + 1], ev[4 * j + 2], ev[4 * j + 3], carry_step, tj);
                 t[4 * j] = tj[0]; t[4 * j + 1] = tj[1]; t[4 * j + 2] = tj[2]; t[4 * j + 3] = tj[3];
             }
 #pragma unroll
@@ -890,8 +906,8 @@ __device__ __forceinline__ void batched_group(
                 int pos = r0[j] - row_first;
 #pragma unroll
                 for (int k = 0; k < kLaneElems; ++k) {
-                    if (ends[4 * j + k]) ytile[pos] = t[4 * j + k];
-                    pos += ends[4 * j + k] ? 1 : 0;
+                    if (ev[4 * j + k]) ytile[pos] = t[4 * j + k];
+                    pos += ev[4 * j + k] ? 1 : 0;
                 }
             }
             for (int i = lane; i < n_rows; i += 64) {
@@ -1292,6 +1308,11 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
                 xv[4 * j + 2] = xw[w.m[j].z >> 16]; xv[4 * j + 3] = xw[w.m[j].w >> 16];
             }
         } else {
+#if HISPMV_TTS_EXPERIMENT == 1            // timing experiment (tools/experiments/r4_tts_phases.sh): no x gathers -- the results are wrong
+#pragma unroll
+        for (int j = 0; j < kE; ++j) xv[j] = 1.0f;
+        (void)rx; (void)base;
+#else
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             xv[4 * j + 0] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].x >> 16) << 2, base, 0));
@@ -1299,6 +1320,7 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
             xv[4 * j + 2] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].z >> 16) << 2, base, 0));
             xv[4 * j + 3] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, (w.m[j].w >> 16) << 2, base, 0));
         }
+#endif
         }
         // products -> staging[slot] (the transposition), THEN the request that reuses the buffer: the slots are read from
         // the buffer itself (16 registers less than keeping them across the request; two buffers + 16 products fit 128)
@@ -1397,10 +1419,14 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         }
         __syncthreads();
         // ---- phase B: row-major order -----------------------------------------------------------------------------
+#if HISPMV_TTS_EXPERIMENT != 2            // (2: timing experiment without the row-order pass -- the results are wrong)
         if (wave < n_chunks) phase_b(wave, ciA, endsA);
         if (wave + n_waves < n_chunks) phase_b(wave + n_waves, ciB, endsB);
         for (int c = wave + 2 * n_waves; c < n_chunks; c += n_waves)
             phase_b(c, load_int2(M.chunk_info + chunk_begin + c), *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + c) * 64 + lane));
+#else
+        (void)endsA; (void)endsB; (void)ciA; (void)ciB;
+#endif
         __syncthreads();
         // rows cut by a chunk boundary: the chunk that holds the row end added its own part; the tails of the chunks
         // before it follow here, in chunk order (one lane per chunk; a block has at most 48 chunks)

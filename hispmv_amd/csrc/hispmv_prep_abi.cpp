@@ -94,6 +94,19 @@ HISPMV_API int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
 }
 
+// inside[nnz]: 1 for the CSR entries whose block of x lies in the window of their workgroup under the launch plan for n_cus CUs
+// (the criterion of the stray split, hispmv_matrix_info.tile_kind 3).  For tests: lets the wavefront model pack the two parts.
+HISPMV_API int hispmv_prep_window_membership(const hispmv_prep* p, int n_cus, uint8_t* inside) {
+    if (!p || !inside || n_cus <= 0) return HISPMV_EINVAL;
+    try {
+        SliceStream copy = build_stream(p->csr);
+        const LaunchPlan plan = make_plan(copy, n_cus);
+        const std::vector<uint8_t> m = window_membership(p->csr, plan);
+        std::copy(m.begin(), m.end(), inside);
+        return HISPMV_OK;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
+
 HISPMV_API int hispmv_prep_dims(const hispmv_prep* p, int64_t d[8]) {
     if (!p || !d) return HISPMV_EINVAL;
     d[0] = p->st.rows; d[1] = p->st.cols; d[2] = p->st.nnz; d[3] = p->st.n_elems; d[4] = p->st.n_slices;

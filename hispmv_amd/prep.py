@@ -154,3 +154,21 @@ def choose_format_from_csr(row_ptr, col_idx, values, rows: int, cols: int, n_cus
         return dict(zip(FORMAT_FIELDS, (int(x) for x in out)))
     finally:
         lib.hispmv_prep_free(p)
+
+
+def window_membership(coo_rows, coo_cols, coo_values, rows: int, cols: int, n_cus: int = 256):
+    """-> (inside, order): `inside[k]` for the matrix's CSR entries (1 = the entry's block of x lies in the LDS window of its
+    workgroup, hispmv_prep_window_membership) and `order`, the permutation that brings the COO triplets into that CSR order."""
+    r = np.ascontiguousarray(coo_rows, dtype=np.int32)
+    c = np.ascontiguousarray(coo_cols, dtype=np.int32)
+    v = np.ascontiguousarray(coo_values, dtype=np.float32)
+    p = C.c_void_p()
+    if lib.hispmv_prep_from_coo(C.byref(p), C.c_void_p(r.ctypes.data), C.c_void_p(c.ctypes.data), C.c_void_p(v.ctypes.data), r.size, rows, cols) != HISPMV_OK:
+        raise ValueError(lib.hispmv_prep_last_error().decode())
+    try:
+        inside = np.zeros(r.size, dtype=np.uint8)
+        if lib.hispmv_prep_window_membership(p, int(n_cus), C.c_void_p(inside.ctypes.data)) != HISPMV_OK:
+            raise ValueError(lib.hispmv_prep_last_error().decode())
+    finally:
+        lib.hispmv_prep_free(p)
+    return inside, np.lexsort((np.arange(r.size), c, r))     # stable: duplicates keep their input order, as in coo_to_csr

@@ -171,7 +171,9 @@ typedef struct hispmv_matrix_info {
     float tts_lines_per_gather;  /* format 1: distinct 128-byte lines of x per 64-lane gather (64 = no lane shares a line) */
     int32_t tile_kind;      /* col_tiles > 1: 1 = tiles are column ranges (col_tile_base / col_tile_width above); 2 = BAND tiles: the same
                                base / width describe ranges of the OFFSET col - row*cols/rows from the scaled diagonal (a banded matrix
-                               whose band is wider than an LDS window, cut along the diagonal); 0 = untiled */
+                               whose band is wider than an LDS window, cut along the diagonal); 3 = STRAY SPLIT: part 0 holds the elements that lie
+                               inside the x window of their workgroup (6-byte elements from LDS), part 1 the few per cent that do not (gathered
+                               through L2 into a partial vector the tail launch adds); 0 = untiled */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);
@@ -215,6 +217,11 @@ int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
  * tile stream, elements that gather x through L2.  Honours the HISPMV_FORMAT / _BAND_TILES / _TTS_GEOMETRY / _COL_TILE_BYTES /
  * _TTS_MIN_NNZ switches like the loader. */
 int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_t out[16]);
+
+/* inside[nnz] (CSR order): 1 for the entries whose 64-byte block of x is held by the x window of their workgroup under the launch
+ * plan for n_cus compute units, 0 for the entries that gather through L2 -- the criterion by which the loader splits a matrix with a
+ * few per cent of stray couplings into a windowed part and a stray part (hispmv_matrix_info.tile_kind 3). */
+int hispmv_prep_window_membership(const hispmv_prep* p, int n_cus, uint8_t* inside);
 
 /* Applies that plan to the prepared stream IN PLACE (the words of LDS-staged groups then carry window
  * indices instead of columns -- or 0x40000000 | column for the elements of the group whose 64-byte block of x

@@ -86,6 +86,14 @@ def test_branches_and_switches():
     # the tall geometry of a tile stream: two column parts
     d = _choose_in_child({"HISPMV_BAND_TILES": "0", "HISPMV_TTS_GEOMETRY": "tall"}, wide)
     assert d["format"] == 1 and d["parts"] == 2 and d["tile_kind"] == 1 and d["tile_width"] > 0
+    # stray couplings: 3 % of a narrow band's entries at random columns -> split into the windowed part and the strays (tile_kind 3);
+    # 12 % strays of the same band still split (<= 15 %), and the switch turns it off
+    strays = "(lambda t: (t[0], np.sort(np.where(np.random.default_rng(5).random(t[1].size) < %s, np.random.default_rng(6).integers(0, 300000, t[1].size), t[1]).reshape(300000, 16), axis=1).reshape(-1).astype(np.int32), t[2]))(_band(300000, 16, 1500))"
+    d = _choose_in_child({}, strays % "0.03")
+    assert (d["format"], d["tile_kind"], d["parts"]) == (0, 3, 2) and d["lds_floats"] > 0
+    assert _choose_in_child({}, strays % "0.12")["tile_kind"] == 3
+    d = _choose_in_child({"HISPMV_STRAY_SPLIT": "0"}, strays % "0.03")
+    assert d["tile_kind"] == 0 and d["parts"] == 1 and d["l2_gather_elems"] > 0
     # fewer compute units, another plan: the decision is a function of (matrix, n_cus) only
     rp, ci, va = _band(200000, 12, 400)
     a = choose_format_from_csr(rp, ci, va, 200000, 200000, 256)

@@ -40,6 +40,13 @@ def prepared_tiles(info, r, c, v, rows, cols):
     r, c, v = np.asarray(r), np.asarray(c), np.asarray(v, np.float32)
     if info["col_tiles"] <= 1:
         return [prep_from_coo(r, c, v, rows, cols)]
+    if info.get("tile_kind") == 3:
+        # stray split: part 0 = the entries inside the x window of their workgroup (under the plan of the WHOLE matrix), part 1 the rest
+        from hispmv_amd.prep import window_membership
+        inside, order = window_membership(r, c, v, rows, cols, 256)
+        keep = np.zeros(r.size, dtype=bool)
+        keep[order] = inside.astype(bool)
+        return [prep_from_coo(r[keep], c[keep], v[keep], rows, cols), prep_from_coo(r[~keep], c[~keep], v[~keep], rows, cols)]
     width, base, n = info["col_tile_width"], info["col_tile_base"], info["col_tiles"]
     # tile_kind 2 (band tiles): base / width are ranges of the OFFSET from the scaled diagonal, col - row*cols/rows
     key = c.astype(np.int64) - (r.astype(np.int64) * cols // rows) if info.get("tile_kind") == 2 else c.astype(np.int64)
@@ -186,12 +193,16 @@ def test_column_tiled_scattered_matrix(fpga):
     assert np.array_equal(y.view(np.uint32), emulate_device(info2, r, c2, v, rows, wide, xw, b, ALPHA, BETA).view(np.uint32))
 
 
-def test_window_of_most_used_blocks_with_l2_spill(pyhispmv_mod, monkeypatch):
-    """x too large for one LDS window (88 % of the entries in 30 000 hot columns, the others anywhere in 400 000; column
+@pytest.mark.parametrize("split", [0, 1])
+def test_window_of_most_used_blocks_with_l2_spill(pyhispmv_mod, monkeypatch, split):
+    """split = 0 (HISPMV_STRAY_SPLIT=0, the plan of rounds 1-3): x too large for one LDS window (88 % of the entries in 30 000 hot columns, the others anywhere in 400 000; column
     tiling switched off so that the single-stream plan runs): the group's window holds its most used 64-byte blocks and
     the remaining elements gather through L2 in the same pass.  Also a banded matrix with a few far-away couplings per row (blocks used
-    once or twice stay out of the window).  Bit-exact against the wavefront model."""
+    once or twice stay out of the window).  Bit-exact against the wavefront model.
+    split = 1 (default since round 4): 12 % / 8 % of the entries outside the windows -> the stray split (tile_kind 3): the windowed
+    part with clean windows, the strays through L2 into a partial vector; bit-exact against the model of the two parts."""
     monkeypatch.setenv("HISPMV_COL_TILE_BYTES", "0")
+    monkeypatch.setenv("HISPMV_STRAY_SPLIT", str(split))
     fpga = pyhispmv_mod.FpgaHandle(*HW)
     rng = np.random.default_rng(21)
     cases = []
@@ -211,13 +222,16 @@ def test_window_of_most_used_blocks_with_l2_spill(pyhispmv_mod, monkeypatch):
         idx = fpga.create_sparse_handle(r, c, v, rows, cols)
         fpga.load_matrices()
         info = fpga.matrix_info(idx)
-        assert info["col_tiles"] == 1 and info["lds_bytes"] > 0, info
+        if split:
+            assert info["tile_kind"] == 3 and info["col_tiles"] == 2 and info["lds_bytes"] > 0, info
+        else:
+            assert info["col_tiles"] == 1 and info["lds_bytes"] > 0, info
         y = np.zeros(rows, np.float32)
         fpga.select_matrix(idx)
         fpga.run_kernel(x, b, y, ALPHA, BETA)
         y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
         assert bwd_err(y, y64, mag) < TOL
-        assert np.array_equal(y.view(np.uint32), emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA).view(np.uint32))
+        assert np.array_equal(y.view(np.uint32), emulate_device(info, r, c, v, rows, cols, x, b, ALPHA, BETA, carry=0 if split else None).view(np.uint32))
     fpga.close()
 
 
@@ -726,3 +740,80 @@ def test_wide_band_is_cut_along_the_diagonal(fpga):
     fpga.spmv_device_batch(batch, ALPHA, BETA)
     fpga.synchronize()
     assert np.array_equal(dy.cpu().numpy().view(np.uint32), ye.view(np.uint32))
+
+
+def test_stray_couplings_are_split_off(fpga):
+    """Stray split (hispmv_matrix_info.tile_kind 3, round 4): a banded matrix with 3 % of its entries at random columns.  Every
+    workgroup has a few elements outside its x window -- unsplit, all of them would take 8-byte elements and the two-way gather (the
+    cliff tools/standin_sweep.py found: PFlow_742 0.70 -> 0.43 of the roofline at 2 % strays).  The loader splits the matrix into the
+    windowed part (100 % compact slices again) and the strays (a small matrix gathered through L2 into a partial vector).  Bitwise
+    equal to the wavefront model of the two parts, single launch, batch entry point and `linear` with 3 vectors; within the 1e-5
+    gate of the fp64 truth; HISPMV_STRAY_SPLIT=0 gives the unsplit plan and the same result within the gate."""
+    import torch
+    rng = np.random.default_rng(91)
+    rows = cols = 300000
+    per_row, half = 16, 1500
+    r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+    c = np.clip(r + rng.integers(-half, half + 1, r.size), 0, cols - 1)
+    stray = rng.random(r.size) < 0.03
+    c[stray] = rng.integers(0, cols, int(stray.sum()))
+    v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
+    r, c = r.astype(np.int32), c.astype(np.int32)
+    x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
+    b = rng.random(rows, dtype=np.float32)
+    idx = fpga.create_sparse_handle(r, c, v, rows, cols)
+    fpga.load_matrices()
+    info = fpga.matrix_info(idx)
+    assert info["format"] == 0 and info["tile_kind"] == 3 and info["col_tiles"] == 2 and info["lds_bytes"] > 0
+    tiles = prepared_tiles(info, r, c, v, rows, cols)
+    assert tiles[0].nnz + tiles[1].nnz == r.size and 0.02 * r.size < tiles[1].nnz < 0.05 * r.size
+    assert info["compact_slices"] >= tiles[0].n_slices - 1              # the windowed part: every slice with 6-byte elements
+    y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
+    ye = emulate_tiles(tiles, x, b, ALPHA, BETA, rows, 0)
+    fpga.select_matrix(idx)
+    for _ in range(2):
+        y = np.full(rows, np.nan, np.float32)
+        fpga.run_kernel(x, b, y, ALPHA, BETA)
+        assert bwd_err(y, y64, mag) < TOL
+        assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
+    dev = torch.device("cuda", 0)
+    dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+    dy = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev)
+    batch = fpga.prepare_batch([idx], [dx.data_ptr()], [db.data_ptr()], [dy.data_ptr()])
+    fpga.spmv_device_batch(batch, ALPHA, BETA)
+    fpga.synchronize()
+    assert np.array_equal(dy.cpu().numpy().view(np.uint32), ye.view(np.uint32))
+    # linear: 3 vectors in one call (alpha = beta = 1), each with the bits of its own one-vector call
+    xs = rng.random(3 * cols, dtype=np.float32)
+    out = fpga.linear(idx, xs, b)
+    for k in range(3):
+        yk64, mk = csr_truth(r, c, v, rows, xs[k * cols:(k + 1) * cols], b, 1.0, 1.0)
+        assert bwd_err(out[k * rows:(k + 1) * rows], yk64, mk) < TOL
+    one = fpga.linear(idx, xs[:cols], b)
+    assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
+
+
+def test_stray_split_can_be_switched_off(pyhispmv_mod, monkeypatch):
+    monkeypatch.setenv("HISPMV_STRAY_SPLIT", "0")
+    rng = np.random.default_rng(92)
+    rows = cols = 200000
+    r = np.repeat(np.arange(rows, dtype=np.int64), 16)
+    c = np.clip(r + rng.integers(-1500, 1501, r.size), 0, cols - 1)
+    stray = rng.random(r.size) < 0.03
+    c[stray] = rng.integers(0, cols, int(stray.sum()))
+    v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
+    h = pyhispmv_mod.FpgaHandle(*HW)
+    try:
+        idx = h.create_sparse_handle(r.astype(np.int32), c.astype(np.int32), v, rows, cols)
+        h.load_matrices()
+        info = h.matrix_info(idx)
+        assert info["tile_kind"] == 0 and info["col_tiles"] == 1
+        x = rng.random(cols, dtype=np.float32)
+        b = rng.random(rows, dtype=np.float32)
+        y = np.full(rows, np.nan, np.float32)
+        h.select_matrix(idx)
+        h.run_kernel(x, b, y, ALPHA, BETA)
+        y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
+        assert bwd_err(y, y64, mag) < TOL
+    finally:
+        h.close()
