@@ -100,3 +100,31 @@ def test_branches_and_switches():
     b = choose_format_from_csr(rp, ci, va, 200000, 200000, 256)
     assert a == b
     assert choose_format_from_csr(rp, ci, va, 200000, 200000, 8)["format"] == 0
+
+
+def test_window_membership_is_the_split_criterion():
+    """hispmv_prep_window_membership: the entries outside their workgroup's x window are exactly the strays of a banded matrix with
+    3 % of its entries re-drawn -- and the loader's two parts hold exactly those two sets (element counts of the decision)."""
+    from hispmv_amd.prep import choose_format_from_csr, window_membership
+    rng = np.random.default_rng(5)
+    rows = 300000
+    rp, ci, va = _band(rows, 16, 1500)
+    ci = ci.reshape(rows, 16).astype(np.int64)
+    far = rng.random(ci.shape) < 0.03
+    ci = np.sort(np.where(far, rng.integers(0, rows, ci.shape), ci), axis=1)
+    r = np.repeat(np.arange(rows, dtype=np.int32), 16)
+    inside, order = window_membership(r, ci.reshape(-1).astype(np.int32), va, rows, rows, 256)
+    assert np.array_equal(order, np.arange(r.size))                       # the triplets were in CSR order already
+    out_share = 1.0 - inside.mean()
+    assert 0.02 < out_share < 0.04
+    # an entry within the band of its row is inside (its block is used by many rows of the group); a far one is not, up to the few
+    # re-drawn columns that land inside the band by chance
+    near = np.abs(ci - np.arange(rows)[:, None]) <= 1500
+    assert inside.reshape(rows, 16)[near].mean() > 0.999 and inside.reshape(rows, 16)[~near].mean() < 0.01
+    d = choose_format_from_csr(rp, ci.reshape(-1).astype(np.int32), va, rows, rows, 256)
+    assert d["tile_kind"] == 3 and d["parts"] == 2
+    # elements of the two parts = inside + outside entries + one filler per row that has no stray (part 1) / no inside entry (part 0)
+    n_out = int((inside == 0).sum())
+    rows_with_out = np.unique(r[inside == 0]).size
+    expected = int(inside.sum()) + n_out + (rows - rows_with_out)
+    assert expected <= d["n_elems"] <= 1.07 * expected                   # (+ the zero-valued elements of row-aligned slices, <= 6 %)
