@@ -92,7 +92,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             m->device_bytes += p.tts.bytes();
         } else {
             m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
-            m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16;
+            m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16 + (int64_t)p.dstream.stray_cols.size() * 4;
             m->compact_slices += p.dstream.compact_slices;
         }
     }
@@ -503,7 +503,19 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                     hh[sl].x_span = (!p.plan.slice_spills.empty() && p.plan.slice_spills[(size_t)sl]) ? 1 : 0;
                     max_rows = std::max(max_rows, nr);
                 }
-                if ((rc = upload(c, m, hh.data(), hh.size(), &dh)) != HISPMV_OK) return rc;
+                if (p.dstream.stray_cols.empty()) {
+                    if ((rc = upload(c, m, hh.data(), hh.size(), &dh)) != HISPMV_OK) return rc;
+                } else {
+                    // stray slots: the columns of every slice's strays (64 x u32 per slice) live BEHIND the headers in one
+                    // allocation -- the kernels reach them as hdr + n_slices, no further pointer to carry around
+                    void* blk = nullptr;
+                    const size_t hb = hh.size() * sizeof(SliceHdr), sb = p.dstream.stray_cols.size() * sizeof(uint32_t);
+                    HIP_TRY(c, hipMalloc(&blk, hb + sb));
+                    m.allocs.push_back(blk);
+                    HIP_TRY(c, hipMemcpyAsync(blk, hh.data(), hb, hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync((char*)blk + hb, p.dstream.stray_cols.data(), sb, hipMemcpyHostToDevice, c->stream));
+                    dh = (const SliceHdr*)blk;
+                }
                 if ((rc = upload(c, m, p.fix_short.data(), p.fix_short.size(), &fs)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.fix_long.data(), p.fix_long.size(), &fl)) != HISPMV_OK) return rc;
                 // carry per slice; {carry, launch tag} granules and the group ticket of the look-back variant
@@ -524,7 +536,8 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 d.carry = (float*)carry; d.gran = (unsigned long long*)gran; d.ticket = (unsigned long long*)ticket;
                 d.err = c->d_err; d.launches = 0; d.ticket_launches = 0;
                 d.n_slices = ns; d.n_groups = (ns + p.plan.group_slices - 1) / p.plan.group_slices;
-                d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads; d.lds_floats = p.plan.lds_floats;
+                d.group_slices = p.plan.group_slices; d.block_threads = p.plan.block_threads;
+                d.lds_floats = p.plan.lds_floats + p.dstream.stray_floats;        // the x window + the wavefronts' stray areas behind it
                 d.ytile_floats = std::min(kSliceElems, (max_rows + 63) & ~63);
                 const size_t lds_plain = (size_t)(d.lds_floats + d.ytile_floats * (d.block_threads / 64)) * 4;
                 if (lds_plain > 160 * 1024 - 256) return fail(c, HISPMV_EINVAL, "internal: launch plan exceeds the LDS of a CU");

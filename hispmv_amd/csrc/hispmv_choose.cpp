@@ -206,8 +206,11 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     // windows and 6-byte elements again, part 1 = A_out (the strays) is a small scattered matrix that gathers through L2 and writes
     // alpha * A_out * x into a partial vector the tail launch adds -- the reference's hybrid row distribution (dense part on the
     // PEs' own rows, the rest through the shared-row network, spmv-helper.cpp:265-347) in the coordinates of the x window.
+    // (Strays that fit the kernel's stray slots -- at most 64 per slice, hispmv_plan.h -- are served there for the price of one
+    // gather per slice: the split is for what the slots do not cover.)
     if (opt.stray_split && opt.format_mode != 1 && whole.lds_floats > 0 && nnz_all >= (1 << 20) &&
-        whole.global_elems * 1000 > all_elems && whole.global_elems * 100 <= 15 * all_elems) {
+        whole.global_elems * 1000 > all_elems && whole.global_elems * 100 <= 15 * all_elems &&
+        stray_slot_coverage(out.parts[0].st, whole) < 0.9) {
         const std::vector<uint8_t> inside = window_membership(csr, out.parts[0].plan);
         auto take = [&](bool want) {
             Csr t;

@@ -27,6 +27,7 @@ constexpr int kCompactMaxIndex = 32768;                   // LDS window floats a
 constexpr int kSliceUnit = 2048;                          // slice sizes and offsets are multiples of this many bytes
 constexpr int kCompactSliceBytes = kSliceElems * 6;       // 6144 = 3 units
 constexpr int kWideSliceBytes = kSliceElems * 8;          // 8192 = 4 units
+constexpr int kStraySlots = 64;                           // stray slots of a compact slice (hispmv_plan.h): x values one wavefront keeps behind the window
 constexpr int kFixShortMax = 32;                          // a row cut over at most this many slices is finished by one thread of the tail launch, a longer chain by a wavefront
 
 // Allocator that leaves trivially constructible elements uninitialised: a packed stream of hundreds of MB is

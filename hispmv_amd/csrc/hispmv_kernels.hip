@@ -340,6 +340,24 @@ __device__ __forceinline__ void slices_group(
     int local = k_slice < n_here ? (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : n_here;
     SliceRaw<COMPACT> w;
     int4 h = int4{0, 0, 0, 0};
+    // STRAY SLOTS (hispmv_plan.h): a compact group whose slices have a few elements outside the window.  The columns of a slice's
+    // strays (<= 64, one per lane, 0xffffffff = none) live behind the headers; their x values are gathered ONE SLICE AHEAD and
+    // written to this wavefront's 64-float stray area behind the window when the slice's turn comes -- the strays' metas index
+    // that area, so the gathers below are plain LDS reads for every element.  Order of the requests: the columns of slice i+2
+    // leave BEFORE the words of slice i+1 and the x values of slice i+1's strays BEFORE them too (vmcnt retires in issue order:
+    // the wait for a slice's words then covers what that slice's turn needs, and nothing waits for anything younger).
+    const bool strays = COMPACT && (__builtin_amdgcn_readfirstlane(g.w) & 2) != 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(hdr + n_slices), 0, strays ? (int)(n_slices * (kStraySlots * 4)) : 0, 0x00020000);
+    float* const stray_area = xs + (lds_floats - n_waves * kStraySlots) + wave * kStraySlots;
+    unsigned sc_next = 0xffffffffu;        // stray columns of this wavefront's NEXT slice
+    float sx_cur = 0.0f;                   // x values of the CURRENT slice's strays (lane k: stray k)
+    if (strays) {
+        const unsigned sc0 = local < n_here ? __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((first + local) * kStraySlots + lane) << 2, 0, 0) : 0xffffffffu;
+        const int k2 = k_slice + n_waves;
+        const int l2 = k2 < n_here ? (k2 + rot >= n_here ? k2 + rot - n_here : k2 + rot) : -1;
+        sc_next = l2 >= 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((first + l2) * kStraySlots + lane) << 2, 0, 0) : 0xffffffffu;
+        sx_cur = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, sc0 << 2, 0, 0));        // (0xffffffff << 2 is out of range: no access)
+    }
     if (local < n_here) {
         // (the header first: a component of it that an instantiation does not use is a dead register hipcc reuses at
         // once -- a write-after-write hazard with the load in flight, and waiting for the YOUNGEST load waits for the
@@ -399,6 +417,13 @@ __device__ __forceinline__ void slices_group(
             __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * out_t0 + beta * out_b0 : alpha * out_t0), ry, out_d0, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(HAS_BETA ? alpha * out_t1 + beta * out_b1 : alpha * out_t1), ry, out_d1, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32((unsigned)f2i(out_carry), rc, out_dc, 0, 0);
+        }
+        float sx_next = 0.0f;
+        if (strays) {
+            // this slice's strays -> the wavefront's stray area (LDS operations of a wavefront execute in order: the gathers
+            // below see them); the x values of the NEXT slice's strays leave now, a whole iteration before they are needed
+            stray_area[lane] = sx_cur;
+            sx_next = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, sc_next << 2, 0, 0));
         }
         float bpre0 = 0.0f, bpre1 = 0.0f;
         if (HAS_BETA) {
@@ -471,6 +496,12 @@ __device__ __forceinline__ void slices_group(
         const long long cur = first + local;
         k_slice += n_waves;
         local = k_slice < n_here ? (k_slice + rot >= n_here ? k_slice + rot - n_here : k_slice + rot) : n_here;
+        if (strays) {                                  // the stray columns of the slice AFTER the next one, ahead of the next one's words
+            const int k2 = k_slice + n_waves;
+            const int l2 = k2 < n_here ? (k2 + rot >= n_here ? k2 + rot - n_here : k2 + rot) : -1;
+            sx_cur = sx_next;
+            sc_next = l2 >= 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((first + l2) * kStraySlots + lane) << 2, 0, 0) : 0xffffffffu;
+        }
         if (local < n_here) {
             h = load_int4(hdr + first + local);       // header first: see the prologue
             request_slice<COMPACT>(w, gbase + (size_t)local * slice_bytes, lane);
@@ -794,10 +825,21 @@ __device__ __forceinline__ void batched_group(
     const char* const gbase = stream + (USE_LDS ? (size_t)(unsigned)__builtin_amdgcn_readfirstlane(g.z) * kSliceUnit
                                                 : (size_t)first * kWideSliceBytes);
 
-    long long slice = first + wave;
+    // the walk of slices_group (rotated start: the packer places a slice's strays by its position in this walk)
+    const int n_here = (int)(last > first ? last - first : 0);
+    const int rot = n_here == 0 ? 0 : (int)((unsigned long long)group * 29ull % (unsigned)n_here);
+    int k_slice = wave;
+    auto local_at = [&](int k) { return k < n_here ? (k + rot >= n_here ? k + rot - n_here : k + rot) : n_here; };
+    long long slice = first + local_at(k_slice);
+    // stray slots (hispmv_plan.h): the columns of the next slice's strays travel with its words; their x values are gathered per
+    // vector at the slice's turn (this kernel is VALU-bound: the exposed round trip hides behind the other wavefronts)
+    const bool strays = COMPACT && (__builtin_amdgcn_readfirstlane(g.w) & 2) != 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(hdr + n_slices), 0, strays ? (int)(n_slices * (kStraySlots * 4)) : 0, 0x00020000);
+    unsigned sc = 0xffffffffu;
     SliceRaw<COMPACT> w;
     int4 h = int4{0, 0, 0, 0};
     if (slice < last) {
+        if (strays) sc = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(slice * kStraySlots + lane) << 2, 0, 0);
         h = load_int4(hdr + slice);
         request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
     }
@@ -825,14 +867,17 @@ __device__ __forceinline__ void batched_group(
             val[4 * j + 2] = i2f((int)w.v[j].z); val[4 * j + 3] = i2f((int)w.v[j].w);
         }
         int r0[kSliceSteps];
-        unsigned long long em[kE];           // row-end masks of the slice's 16 element positions (wave-uniform)
+        // (Round 4: taking each vector's row-end masks through an opaque copy, so that the 4 x 7 scan flag words are recomputed per
+        // vector instead of living -- spilled -- across the unrolled vector loop, cut the SGPR reloads inside the loop from 739 to
+        // 520 per slice (tools/spill_report.py) and measured no gain: the 8192 x 8192 layer with 8 vectors 54.4 us against 50.8.)
+        bool ends[kE];
 #pragma unroll
         for (int j = 0; j < kSliceSteps; ++j) {
             int below = 0, total = 0;
 #pragma unroll
             for (int k = 0; k < kLaneElems; ++k) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64((c[4 * j + k] & kRowEndBit) != 0);
-                em[4 * j + k] = m;
+                ends[4 * j + k] = (c[4 * j + k] & kRowEndBit) != 0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ends[4 * j + k]);
                 below += lanes_below(m);
                 total += __builtin_popcountll(m);
             }
@@ -840,6 +885,14 @@ __device__ __forceinline__ void batched_group(
             row += total;
         }
         const long long cur = slice;
+        if (strays) {
+            float sx[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                sx[v] = i2f((int)__builtin_amdgcn_raw_buffer_load_b32(rx, sc == 0xffffffffu ? kNoAccess : (sc + (unsigned)v * (unsigned)cols) << 2, 0, 0));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) (xs + v * lds_floats + (lds_floats - n_waves * kStraySlots) + wave * kStraySlots)[lane] = sx[v];
+        }
 
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -874,31 +927,21 @@ __device__ __forceinline__ void batched_group(
             if (v == NV - 1) {
                 // the slice's values and metas live in val[] / c[]: request this wavefront's next slice behind the last
                 // vector's gathers (vmcnt retires in issue order: waiting for the gathers must not wait for the prefetch)
-                slice += n_waves;
+                k_slice += n_waves;
+                slice = first + local_at(k_slice);
                 if (slice < last) {
+                    if (strays) sc = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(slice * kStraySlots + lane) << 2, 0, 0);
                     h = load_int4(hdr + slice);
                     request_slice<COMPACT>(w, gbase + (size_t)(slice - first) * slice_bytes, lane);
                 }
             }
             float t[kE];
             float carry_step = 0.0f;
-            // The row-end masks are the same for every vector, and hipcc hoisted everything derived from them -- the 4 x 7 scan flag
-            // words of scan_flags() -- out of the unrolled vector loop: 56 more scalar registers live across it than the SGPR
-            // file has, 179 spilled SGPRs and ~740 v_readlane reloads per slice inside the loop (tools/spill_report.py).  Each
-            // vector therefore takes its masks through an opaque copy: the flag words are recomputed per vector on the scalar
-            // unit (40 SALU instructions per step) and die with it.
-            bool ev[kE];
-#pragma unroll
-            for (int i = 0; i < kE; ++i) {
-                unsigned long long m = em[i];
-                asm volatile("" : "+s"(m));
-                ev[i] = __builtin_amdgcn_inverse_ballot_w64(m);
-            }
 #pragma unroll
             for (int j = 0; j < kSliceSteps; ++j) {
                 const float pj[kLaneElems] = {val[4 * j] * xg[4 * j], val[4 * j + 1] * xg[4 * j + 1], val[4 * j + 2] * xg[4 * j + 2], val[4 * j + 3] * xg[4 * j + 3]};
                 float tj[kLaneElems];
-                scan_step(pj, ev[4 * j], ev[4 * j + 1], ev[4 * j + 2], ev[4 * j + 3], carry_step, tj);
+                scan_step(pj, ends[4 * j], ends[4 * j + 1], ends[4 * j + 2], ends[4 * j + 3], carry_step, tj);
                 t[4 * j] = tj[0]; t[4 * j + 1] = tj[1]; t[4 * j + 2] = tj[2]; t[4 * j + 3] = tj[3];
             }
 #pragma unroll
@@ -906,8 +949,8 @@ __device__ __forceinline__ void batched_group(
                 int pos = r0[j] - row_first;
 #pragma unroll
                 for (int k = 0; k < kLaneElems; ++k) {
-                    if (ev[4 * j + k]) ytile[pos] = t[4 * j + k];
-                    pos += ev[4 * j + k] ? 1 : 0;
+                    if (ends[4 * j + k]) ytile[pos] = t[4 * j + k];
+                    pos += ends[4 * j + k] ? 1 : 0;
                 }
             }
             for (int i = lane; i < n_rows; i += 64) {

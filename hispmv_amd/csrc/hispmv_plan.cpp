@@ -141,6 +141,8 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         if (n < 512 && !force) break;
         Cfg c = c0;
         c.cap = std::min(c.cap, ((160 * 1024 - 4096) / c.per_cu - ytile * (c.threads / 64) * 4) / 4);   // 4 KiB: look-back mailbox, static LDS
+        // (a window never grows into the index range of the wavefronts' stray areas: hispmv_plan.h, stray slots)
+        c.cap = std::min(c.cap, kCompactMaxIndex - (c.threads / 64) * kStraySlots);
         c.cap &= ~(kFragBlock - 1);
         if (c.cap < 256) continue;
         int64_t G = c.slices;
@@ -245,7 +247,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
                 const uint32_t idx = inside ? (uint32_t)(it - blocks.begin()) * kFragBlock + (uint32_t)(col % kFragBlock)
                                             : (kGlobalColBit | (uint32_t)col);
                 w[i] = (w[i] & 0x80000000ffffffffull) | ((uint64_t)idx << 32);
-                if (!inside) best.slice_spills[(size_t)(s0 + i / kSliceElems)] = 1;
+                if (!inside) { uint16_t& q = best.slice_spills[(size_t)(s0 + i / kSliceElems)]; if (q < 0xffff) ++q; }
             }
         }
     }
@@ -264,27 +266,71 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
     return best;
 }
 
+namespace {
+// stray slots: plans whose wavefronts walk several slices (a one-round plan may run the look-back variant, whose walk is not
+// rotated: the packer could not know a slice's position), window + stray areas within what a compact meta can index and within
+// the LDS share the plan was sized for (make_plan: 160 KiB less 4 KiB, per resident workgroup)
+bool stray_slots_possible(const LaunchPlan& plan) {
+    const char* env = std::getenv("HISPMV_STRAY_SLOTS");          // (read per call: tests switch it inside one process)
+    const bool stray_env = !(env && std::atoi(env) == 0);
+    const int n_waves = plan.block_threads / 64;
+    return stray_env && !plan.slice_spills.empty() && plan.group_slices > n_waves && plan.lds_floats > 0 &&
+           plan.lds_floats + n_waves * kStraySlots <= kCompactMaxIndex &&
+           ((int64_t)plan.lds_floats + n_waves * kStraySlots + (int64_t)plan.ytile_floats * n_waves) * 4 <= (160 * 1024 - 4096) / std::max(1, plan.per_cu);
+}
+// a group with elements outside its window keeps 6-byte elements when every one of its slices has at most kStraySlots of them
+bool stray_group_ok(const LaunchPlan& plan, int64_t g, int64_t n) {
+    const GroupDesc& gd = plan.groups[(size_t)g];
+    if (gd.frag_count <= 0 || gd.n_global <= 0) return false;
+    const int64_t G = plan.group_slices, s0 = g * G, s1 = std::min(n, s0 + G);
+    for (int64_t sl = s0; sl < s1; ++sl) if (plan.slice_spills[(size_t)sl] > kStraySlots) return false;
+    return true;
+}
+}  // namespace
+
+double stray_slot_coverage(const SliceStream& st, const LaunchPlan& plan) {
+    if (!stray_slots_possible(plan)) return 0.0;
+    int64_t all = 0, covered = 0;
+    for (int64_t g = 0; g < (int64_t)plan.groups.size(); ++g) {
+        const int64_t ngl = plan.groups[(size_t)g].frag_count > 0 ? plan.groups[(size_t)g].n_global : 0;
+        all += ngl;
+        if (ngl > 0 && stray_group_ok(plan, g, st.n_slices)) covered += ngl;
+    }
+    return all > 0 ? (double)covered / (double)all : 0.0;
+}
+
 DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan) {
     DeviceStream d;
     const int64_t n = st.n_slices, G = plan.group_slices;
     const int64_t ng = std::max<int64_t>((n + G - 1) / G, 1);
+    const int n_waves = plan.block_threads / 64;
     d.groups.assign((size_t)ng * 4, 0);
     std::vector<int64_t> off((size_t)ng + 1, 0);
-    std::vector<uint8_t> compact((size_t)ng, 0);
+    std::vector<uint8_t> compact((size_t)ng, 0);       // 1 compact, 3 compact with stray slots
+    const bool stray_possible = stray_slots_possible(plan);
+    bool any_stray = false;
     for (int64_t g = 0; g < ng; ++g) {
         const GroupDesc gd = (size_t)g < plan.groups.size() ? plan.groups[(size_t)g] : GroupDesc{0, 0, 0, 0};
         const int64_t s0 = g * G, s1 = std::min(n, s0 + G);
         compact[(size_t)g] = gd.frag_count > 0 && gd.n_global == 0 && gd.lds_floats <= kCompactMaxIndex;
+        if (!compact[(size_t)g] && stray_possible && (size_t)g < plan.groups.size() && stray_group_ok(plan, g, n)) { compact[(size_t)g] = 3; any_stray = true; }
         off[(size_t)g + 1] = off[(size_t)g] + std::max<int64_t>(s1 - s0, 0) * (compact[(size_t)g] ? kCompactSliceBytes : kWideSliceBytes);
         d.groups[(size_t)g * 4 + 0] = gd.frag_begin; d.groups[(size_t)g * 4 + 1] = gd.frag_count;
         d.groups[(size_t)g * 4 + 2] = (int32_t)(off[(size_t)g] / kSliceUnit); d.groups[(size_t)g * 4 + 3] = compact[(size_t)g];
         if (compact[(size_t)g]) d.compact_slices += std::max<int64_t>(s1 - s0, 0);
+        if (compact[(size_t)g] == 3) d.stray_slices += std::max<int64_t>(s1 - s0, 0);
     }
     if (off[(size_t)ng] / kSliceUnit > INT32_MAX) throw std::length_error("stream larger than 4 TiB");
     d.bytes.resize((size_t)off[(size_t)ng]);
+    if (any_stray) {
+        d.stray_floats = n_waves * kStraySlots;
+        d.stray_cols.assign((size_t)n * kStraySlots, 0xffffffffu);
+    }
 #pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 4)
     for (int64_t g = 0; g < ng; ++g) {
         const int64_t s0 = g * G, s1 = std::min(n, s0 + G);
+        const int64_t n_here = s1 - s0;
+        const int64_t rot = n_here > 0 ? (int64_t)(((unsigned long long)g * 29ull) % (unsigned long long)n_here) : 0;   // the kernel's walk (slices_group)
         for (int64_t sl = s0; sl < s1; ++sl) {
             const uint64_t* w = st.words.data() + sl * kSliceElems;
             uint8_t* base = d.bytes.data() + off[(size_t)g] + (sl - s0) * (compact[(size_t)g] ? kCompactSliceBytes : kWideSliceBytes);
@@ -292,9 +338,18 @@ DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan) {
             for (int i = 0; i < kSliceElems; ++i) vals[i] = (uint32_t)w[i];
             if (compact[(size_t)g]) {
                 uint16_t* meta = (uint16_t*)(base + kSliceElems * 4);
+                // position of the slice in its workgroup's walk -> the wavefront that takes it -> that wavefront's stray area
+                const int64_t pos = ((sl - s0) - rot + n_here) % n_here;
+                const uint32_t area = (uint32_t)plan.lds_floats + (uint32_t)(pos % n_waves) * kStraySlots;
+                uint32_t k = 0;
                 for (int i = 0; i < kSliceElems; ++i) {
                     const uint32_t m = (uint32_t)(w[i] >> 32);
-                    meta[i] = (uint16_t)((m & 0x7fffu) | ((m & kRowEndBit) ? kCompactEndBit : 0u));
+                    uint32_t idx = m & 0x7fffu;
+                    if (m & kGlobalColBit) {                     // a stray: its x value waits in the wavefront's stray area
+                        d.stray_cols[(size_t)sl * kStraySlots + k] = m & ~(kRowEndBit | kGlobalColBit);
+                        idx = area + k++;
+                    }
+                    meta[i] = (uint16_t)(idx | ((m & kRowEndBit) ? kCompactEndBit : 0u));
                 }
             } else {
                 uint32_t* meta = (uint32_t*)(base + kSliceElems * 4);

@@ -41,7 +41,7 @@ struct LaunchPlan {
     int per_cu = 4;            // resident workgroups per CU the plan was sized for
     std::vector<GroupDesc> groups;
     std::vector<Frag> frags;
-    std::vector<uint8_t> slice_spills;   // per slice: 1 = some of its elements gather through L2 (empty: none does)
+    std::vector<uint16_t> slice_spills;  // per slice: how many of its elements lie outside the group's window (empty: none anywhere)
     int64_t staged_floats = 0; // sum over groups (diagnostics)
     int64_t global_elems = 0;  // elements of staged groups that still gather through L2
 };
@@ -55,11 +55,22 @@ int ytile_floats_for(const SliceStream& st);
 
 // Device form of a planned stream (hispmv_format.h: structure-of-arrays slices, compact or wide per GROUP -- a group is
 // compact when it has a window and none of its elements lies outside it).
+// STRAY SLOTS (round 4): a group whose slices each have at most kStraySlots elements outside the window stays COMPACT.  The x
+// values of a slice's strays are fetched by the wavefront that owns the slice -- one lane per stray, from the slice's list of stray
+// columns -- into that wavefront's 64-float stray area behind the window, and the strays' 16-bit metas index that area: stray k of
+// the slice at position p of its workgroup's walk sits at window index  lds_floats + (p mod wavefronts) * 64 + k  (the walk is the
+// kernel's: slice s of group g is at position (s - rot + n) mod n with rot = 29 g mod n, n = slices of the group).  Without them one
+// stray element makes its whole group take 8-byte elements and the two-way gather: the PFlow_742 stand-in falls from 0.70 to 0.43
+// of the roofline when 2 % of its entries are re-drawn at random columns (profiles/r4_standin_sweep*.json).
 struct DeviceStream {
     std::vector<uint8_t, DefaultInitAllocator<uint8_t>> bytes;   // the slices, group after group (uninitialised until the packing loop writes them)
-    std::vector<int32_t> groups;         // n_groups x {frag_begin, frag_count, offset of the group's first slice in kSliceUnit, 1 = compact}
-    int64_t compact_slices = 0;
+    std::vector<int32_t> groups;         // n_groups x {frag_begin, frag_count, offset of the group's first slice in kSliceUnit, 1 = compact | 2 = has stray slots}
+    std::vector<uint32_t> stray_cols;    // n_slices x kStraySlots columns (0xffffffff = unused), empty when no group uses stray slots
+    int stray_floats = 0;                // LDS floats of the stray areas (wavefronts x kStraySlots) behind the window, 0 = none
+    int64_t compact_slices = 0, stray_slices = 0;
 };
 DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan);
+// Share of the plan's elements outside their windows that stray slots will serve (groups whose slices have <= kStraySlots each).
+double stray_slot_coverage(const SliceStream& st, const LaunchPlan& plan);
 
 }  // namespace hispmv

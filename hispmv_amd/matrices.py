@@ -382,6 +382,13 @@ def benchmark_set(names=None, uniform: bool = False, seed_shift: int = 0):
         if real is not None and seed_shift == 0:
             out.append(dict(name=name, source="file:" + str(real), path=str(real)))
             continue
+        # HISPMV_BENCH_VARIANT=<variant of STANDIN_VARIANTS> (experiments): the mesh-origin matrices under that perturbation
+        import os
+        variant = os.environ.get("HISPMV_BENCH_VARIANT", "")
+        if variant and fam == "fem" and not uniform and seed_shift == 0:
+            _r, _c, rp, ci, va = standin_variant(name, variant)
+            out.append(dict(name=name, source=f"synthetic:fem:{variant}", family=fam, rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
+            continue
         rp, ci, va, used = make_standin(name, rows, nnz, fam, par, zlib.crc32(name.encode()) + seed_shift, uniform)
         out.append(dict(name=name, source=f"synthetic:{used}", family=fam, rows=rows, cols=rows, nnz=int(rp[-1]), rp=rp, ci=ci, va=va))
     return out

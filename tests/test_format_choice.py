@@ -89,10 +89,14 @@ def test_branches_and_switches():
     # stray couplings: 3 % of a narrow band's entries at random columns -> split into the windowed part and the strays (tile_kind 3);
     # 12 % strays of the same band still split (<= 15 %), and the switch turns it off
     strays = "(lambda t: (t[0], np.sort(np.where(np.random.default_rng(5).random(t[1].size) < %s, np.random.default_rng(6).integers(0, 300000, t[1].size), t[1]).reshape(300000, 16), axis=1).reshape(-1).astype(np.int32), t[2]))(_band(300000, 16, 1500))"
+    # 3 % (31 per slice): the kernel's stray slots serve them (<= 64 per slice) -- one stream, every slice compact; without the slots:
+    # the split; 12 % (123 per slice): beyond the slots, split; and the switch turns the split off
     d = _choose_in_child({}, strays % "0.03")
+    assert (d["format"], d["tile_kind"], d["parts"]) == (0, 0, 1) and d["lds_floats"] > 0 and d["l2_gather_elems"] > 0
+    d = _choose_in_child({"HISPMV_STRAY_SLOTS": "0"}, strays % "0.03")
     assert (d["format"], d["tile_kind"], d["parts"]) == (0, 3, 2) and d["lds_floats"] > 0
     assert _choose_in_child({}, strays % "0.12")["tile_kind"] == 3
-    d = _choose_in_child({"HISPMV_STRAY_SPLIT": "0"}, strays % "0.03")
+    d = _choose_in_child({"HISPMV_STRAY_SPLIT": "0"}, strays % "0.12")
     assert d["tile_kind"] == 0 and d["parts"] == 1 and d["l2_gather_elems"] > 0
     # fewer compute units, another plan: the decision is a function of (matrix, n_cus) only
     rp, ci, va = _band(200000, 12, 400)
@@ -104,19 +108,20 @@ def test_branches_and_switches():
 
 def test_window_membership_is_the_split_criterion():
     """hispmv_prep_window_membership: the entries outside their workgroup's x window are exactly the strays of a banded matrix with
-    3 % of its entries re-drawn -- and the loader's two parts hold exactly those two sets (element counts of the decision)."""
+    10 % of its entries re-drawn (more than the kernel's stray slots take) -- and the loader's two parts hold exactly those two sets
+    (element counts of the decision)."""
     from hispmv_amd.prep import choose_format_from_csr, window_membership
     rng = np.random.default_rng(5)
     rows = 300000
     rp, ci, va = _band(rows, 16, 1500)
     ci = ci.reshape(rows, 16).astype(np.int64)
-    far = rng.random(ci.shape) < 0.03
+    far = rng.random(ci.shape) < 0.10
     ci = np.sort(np.where(far, rng.integers(0, rows, ci.shape), ci), axis=1)
     r = np.repeat(np.arange(rows, dtype=np.int32), 16)
     inside, order = window_membership(r, ci.reshape(-1).astype(np.int32), va, rows, rows, 256)
     assert np.array_equal(order, np.arange(r.size))                       # the triplets were in CSR order already
     out_share = 1.0 - inside.mean()
-    assert 0.02 < out_share < 0.04
+    assert 0.08 < out_share < 0.12
     # an entry within the band of its row is inside (its block is used by many rows of the group); a far one is not, up to the few
     # re-drawn columns that land inside the band by chance
     near = np.abs(ci - np.arange(rows)[:, None]) <= 1500

@@ -742,59 +742,72 @@ def test_wide_band_is_cut_along_the_diagonal(fpga):
     assert np.array_equal(dy.cpu().numpy().view(np.uint32), ye.view(np.uint32))
 
 
-def test_stray_couplings_are_split_off(fpga):
-    """Stray split (hispmv_matrix_info.tile_kind 3, round 4): a banded matrix with 3 % of its entries at random columns.  Every
-    workgroup has a few elements outside its x window -- unsplit, all of them would take 8-byte elements and the two-way gather (the
-    cliff tools/standin_sweep.py found: PFlow_742 0.70 -> 0.43 of the roofline at 2 % strays).  The loader splits the matrix into the
-    windowed part (100 % compact slices again) and the strays (a small matrix gathered through L2 into a partial vector).  Bitwise
-    equal to the wavefront model of the two parts, single launch, batch entry point and `linear` with 3 vectors; within the 1e-5
-    gate of the fp64 truth; HISPMV_STRAY_SPLIT=0 gives the unsplit plan and the same result within the gate."""
+@pytest.mark.parametrize("slots", [1, 0])
+def test_stray_couplings(pyhispmv_mod, monkeypatch, slots):
+    """A banded matrix with 3 % of its entries at random columns: every workgroup has a few elements outside its x window -- unsplit
+    and without stray slots all of them would take 8-byte elements and the two-way gather (the cliff tools/standin_sweep.py found:
+    PFlow_742 0.70 -> 0.43 of the roofline at 2 % strays).
+    slots = 1 (default): STRAY SLOTS (hispmv_plan.h) -- every slice stays compact, the owning wavefront fetches its slice's strays
+    (<= 64) into its stray area behind the window one slice ahead; one stream, tile_kind 0.
+    slots = 0 (HISPMV_STRAY_SLOTS=0): the STRAY SPLIT (tile_kind 3) -- windowed part + strays through L2 into a partial vector.
+    Both: bitwise equal to the wavefront model, single launch, batch entry point and `linear` with 3 vectors; within the 1e-5 gate."""
     import torch
-    rng = np.random.default_rng(91)
-    rows = cols = 300000
-    per_row, half = 16, 1500
-    r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
-    c = np.clip(r + rng.integers(-half, half + 1, r.size), 0, cols - 1)
-    stray = rng.random(r.size) < 0.03
-    c[stray] = rng.integers(0, cols, int(stray.sum()))
-    v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
-    r, c = r.astype(np.int32), c.astype(np.int32)
-    x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
-    b = rng.random(rows, dtype=np.float32)
-    idx = fpga.create_sparse_handle(r, c, v, rows, cols)
-    fpga.load_matrices()
-    info = fpga.matrix_info(idx)
-    assert info["format"] == 0 and info["tile_kind"] == 3 and info["col_tiles"] == 2 and info["lds_bytes"] > 0
-    tiles = prepared_tiles(info, r, c, v, rows, cols)
-    assert tiles[0].nnz + tiles[1].nnz == r.size and 0.02 * r.size < tiles[1].nnz < 0.05 * r.size
-    assert info["compact_slices"] >= tiles[0].n_slices - 1              # the windowed part: every slice with 6-byte elements
-    y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
-    ye = emulate_tiles(tiles, x, b, ALPHA, BETA, rows, 0)
-    fpga.select_matrix(idx)
-    for _ in range(2):
-        y = np.full(rows, np.nan, np.float32)
-        fpga.run_kernel(x, b, y, ALPHA, BETA)
-        assert bwd_err(y, y64, mag) < TOL
-        assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
-    dev = torch.device("cuda", 0)
-    dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
-    dy = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev)
-    batch = fpga.prepare_batch([idx], [dx.data_ptr()], [db.data_ptr()], [dy.data_ptr()])
-    fpga.spmv_device_batch(batch, ALPHA, BETA)
-    fpga.synchronize()
-    assert np.array_equal(dy.cpu().numpy().view(np.uint32), ye.view(np.uint32))
-    # linear: 3 vectors in one call (alpha = beta = 1), each with the bits of its own one-vector call
-    xs = rng.random(3 * cols, dtype=np.float32)
-    out = fpga.linear(idx, xs, b)
-    for k in range(3):
-        yk64, mk = csr_truth(r, c, v, rows, xs[k * cols:(k + 1) * cols], b, 1.0, 1.0)
-        assert bwd_err(out[k * rows:(k + 1) * rows], yk64, mk) < TOL
-    one = fpga.linear(idx, xs[:cols], b)
-    assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
+    monkeypatch.setenv("HISPMV_STRAY_SLOTS", str(slots))
+    fpga = pyhispmv_mod.FpgaHandle(*HW)
+    try:
+        rng = np.random.default_rng(91)
+        rows = cols = 300000
+        per_row, half = 16, 1500
+        r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+        c = np.clip(r + rng.integers(-half, half + 1, r.size), 0, cols - 1)
+        stray = rng.random(r.size) < 0.03
+        c[stray] = rng.integers(0, cols, int(stray.sum()))
+        v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
+        r, c = r.astype(np.int32), c.astype(np.int32)
+        x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
+        b = rng.random(rows, dtype=np.float32)
+        idx = fpga.create_sparse_handle(r, c, v, rows, cols)
+        fpga.load_matrices()
+        info = fpga.matrix_info(idx)
+        tiles = prepared_tiles(info, r, c, v, rows, cols)
+        if slots:
+            assert info["format"] == 0 and info["tile_kind"] == 0 and info["col_tiles"] == 1 and info["lds_bytes"] > 0, info
+            assert info["compact_slices"] == info["n_slices"]                   # 6-byte elements everywhere, strays included
+        else:
+            assert info["format"] == 0 and info["tile_kind"] == 3 and info["col_tiles"] == 2 and info["lds_bytes"] > 0, info
+            assert tiles[0].nnz + tiles[1].nnz == r.size and 0.02 * r.size < tiles[1].nnz < 0.05 * r.size
+        y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
+        ye = emulate_tiles(tiles, x, b, ALPHA, BETA, rows, 0 if not slots else info["carry_lookback"])
+        fpga.select_matrix(idx)
+        for _ in range(2):
+            y = np.full(rows, np.nan, np.float32)
+            fpga.run_kernel(x, b, y, ALPHA, BETA)
+            assert bwd_err(y, y64, mag) < TOL
+            assert np.array_equal(y.view(np.uint32), ye.view(np.uint32))
+        dev = torch.device("cuda", 0)
+        dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+        dy = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev)
+        batch = fpga.prepare_batch([idx], [dx.data_ptr()], [db.data_ptr()], [dy.data_ptr()])
+        fpga.spmv_device_batch(batch, ALPHA, BETA)
+        fpga.synchronize()
+        yb = dy.cpu().numpy()
+        assert bwd_err(yb, y64, mag) < TOL
+        assert np.array_equal(yb.view(np.uint32), emulate_tiles(tiles, x, b, ALPHA, BETA, rows, 0).view(np.uint32))
+        # linear: 3 vectors in one call (alpha = beta = 1), each with the bits of its own one-vector call
+        xs = rng.random(3 * cols, dtype=np.float32)
+        out = fpga.linear(idx, xs, b)
+        for k in range(3):
+            yk64, mk = csr_truth(r, c, v, rows, xs[k * cols:(k + 1) * cols], b, 1.0, 1.0)
+            assert bwd_err(out[k * rows:(k + 1) * rows], yk64, mk) < TOL
+        one = fpga.linear(idx, xs[:cols], b)
+        assert np.array_equal(one.view(np.uint32), out[:rows].view(np.uint32))
+    finally:
+        fpga.close()
 
 
-def test_stray_split_can_be_switched_off(pyhispmv_mod, monkeypatch):
+def test_strays_without_slots_and_without_split_take_the_two_way_gather(pyhispmv_mod, monkeypatch):
     monkeypatch.setenv("HISPMV_STRAY_SPLIT", "0")
+    monkeypatch.setenv("HISPMV_STRAY_SLOTS", "0")
     rng = np.random.default_rng(92)
     rows = cols = 200000
     r = np.repeat(np.arange(rows, dtype=np.int64), 16)
@@ -807,7 +820,7 @@ def test_stray_split_can_be_switched_off(pyhispmv_mod, monkeypatch):
         idx = h.create_sparse_handle(r.astype(np.int32), c.astype(np.int32), v, rows, cols)
         h.load_matrices()
         info = h.matrix_info(idx)
-        assert info["tile_kind"] == 0 and info["col_tiles"] == 1
+        assert info["tile_kind"] == 0 and info["col_tiles"] == 1 and info["compact_slices"] < 0.1 * info["n_slices"]
         x = rng.random(cols, dtype=np.float32)
         b = rng.random(rows, dtype=np.float32)
         y = np.full(rows, np.nan, np.float32)
@@ -815,5 +828,6 @@ def test_stray_split_can_be_switched_off(pyhispmv_mod, monkeypatch):
         h.run_kernel(x, b, y, ALPHA, BETA)
         y64, mag = csr_truth(r, c, v, rows, x, b, ALPHA, BETA)
         assert bwd_err(y, y64, mag) < TOL
+        assert np.array_equal(y.view(np.uint32), emulate_device(info, r.astype(np.int32), c.astype(np.int32), v, rows, cols, x, b, ALPHA, BETA).view(np.uint32))
     finally:
         h.close()
