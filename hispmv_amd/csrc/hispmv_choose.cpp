@@ -208,7 +208,9 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     // PEs' own rows, the rest through the shared-row network, spmv-helper.cpp:265-347) in the coordinates of the x window.
     // (Strays that fit the kernel's stray slots -- at most 64 per slice, hispmv_plan.h -- are served there for the price of one
     // gather per slice: the split is for what the slots do not cover.)
-    if (opt.stray_split && opt.format_mode != 1 && whole.lds_floats > 0 && nnz_all >= (1 << 20) &&
+    // (not for the small-matrix class -- 256-thread plans: crystk03 with 2 % strays 0.152 -> 0.109 of the roofline split, two grids
+    // and a tail around a 10 us kernel)
+    if (opt.stray_split && opt.format_mode != 1 && whole.lds_floats > 0 && nnz_all >= (1 << 20) && whole.block_threads >= 512 &&
         whole.global_elems * 1000 > all_elems && whole.global_elems * 100 <= 15 * all_elems &&
         stray_slot_coverage(out.parts[0].st, whole) < 0.9) {
         const std::vector<uint8_t> inside = window_membership(csr, out.parts[0].plan);

@@ -163,8 +163,9 @@ typedef struct hispmv_matrix_info {
     int32_t col_tile_width; /* columns per tile when col_tiles > 1, else 0 */
     int32_t col_tile_base;  /* tile t covers columns [base + t*width, base + (t+1)*width) of the range holding 99.8 % of the
                                elements; the first tile also takes every column below, the last every column above */
-    int32_t compact_slices; /* slices stored with 6-byte elements (fp32 value + 16-bit {rowEnd, index into the LDS window of x}); the
-                               others take 8 bytes per element (32-bit meta) */
+    int32_t compact_slices; /* slices stored with 6-byte elements (fp32 value + 16-bit {rowEnd, index into the LDS window of x -- or into the
+                               owning wavefront's stray area behind it, for up to 64 elements per slice whose column lies outside the window});
+                               the others take 8 bytes per element (32-bit meta) */
     int32_t format;         /* 0 = slice stream (rows in order, segmented scan); 1 = transposed tile stream (scattered short-row matrices:
                                row tiles with LDS accumulators, elements streamed sorted by column, transposed through LDS; n_slices then
                                counts its 1024-word slices, n_split_rows the rows cut into pieces: longer than a tile and a quarter) */
