@@ -165,6 +165,7 @@ struct hispmv_prep {
     hispmv::SliceStream st;
     hispmv::LaunchPlan plan;
     hispmv::TtsStream tts;
+    hispmv::DeviceStream dstream;     // hispmv_prep_device_stream: the planned stream in its device layout
 };
 
 

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
 // SpMVs -- the 20 matrices of the benchmark set, the heads of a model -- then share launch ramps and tails instead of
 // paying 6-20 us of launch latency each.  All matrices of a launch have the same workgroup size.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
     int k = 0;
 #pragma unroll 1
     while (k + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[k + 1]) ++k;

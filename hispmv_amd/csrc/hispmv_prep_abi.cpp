@@ -129,6 +129,26 @@ HISPMV_API int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[
     counts[0] = (int64_t)p->plan.groups.size(); counts[1] = (int64_t)p->plan.frags.size();
     return HISPMV_OK;
 }
+// The device layout of the stream under the plan hispmv_prep_apply_plan computed (call that first): counts = {bytes, groups,
+// compact slices, slices with stray slots, stray-area floats, window floats of the plan}; arrays through hispmv_prep_device_array.
+HISPMV_API int hispmv_prep_device_stream(hispmv_prep* p, int64_t counts[6]) {
+    if (!p || !counts) return HISPMV_EINVAL;
+    try {
+        p->dstream = pack_device_stream(p->st, p->plan);
+        counts[0] = (int64_t)p->dstream.bytes.size(); counts[1] = (int64_t)p->dstream.groups.size() / 4; counts[2] = p->dstream.compact_slices;
+        counts[3] = p->dstream.stray_slices; counts[4] = p->dstream.stray_floats; counts[5] = p->plan.lds_floats;
+        return HISPMV_OK;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
+HISPMV_API const void* hispmv_prep_device_array(const hispmv_prep* p, int which) {
+    if (!p) return nullptr;
+    switch (which) {
+        case 0: return p->dstream.bytes.data();
+        case 1: return p->dstream.groups.data();
+        case 2: return p->dstream.stray_cols.data();
+        default: return nullptr;
+    }
+}
 HISPMV_API const int32_t* hispmv_prep_groups(const hispmv_prep* p) { return (const int32_t*)p->plan.groups.data(); }
 HISPMV_API const int32_t* hispmv_prep_frags(const hispmv_prep* p) { return (const int32_t*)p->plan.frags.data(); }
 

@@ -172,3 +172,41 @@ def window_membership(coo_rows, coo_cols, coo_values, rows: int, cols: int, n_cu
     finally:
         lib.hispmv_prep_free(p)
     return inside, np.lexsort((np.arange(r.size), c, r))     # stable: duplicates keep their input order, as in coo_to_csr
+
+
+def device_layout_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int, n_cus: int = 256) -> dict:
+    """The stream of a matrix as the device gets it (hispmv_prep_device_stream), host-only: -> dict with the host words before
+    planning (`words`), the plan (`threads`, `group_slices`, `window_floats`, `stray_floats`, `groups`, `frags`) and the device
+    arrays (`bytes` u8, `dgroups` [n,4], `stray_cols` [n_slices,64] or empty)."""
+    r = np.ascontiguousarray(coo_rows, dtype=np.int32)
+    c = np.ascontiguousarray(coo_cols, dtype=np.int32)
+    v = np.ascontiguousarray(coo_values, dtype=np.float32)
+    p = C.c_void_p()
+    if lib.hispmv_prep_from_coo(C.byref(p), C.c_void_p(r.ctypes.data), C.c_void_p(c.ctypes.data), C.c_void_p(v.ctypes.data), r.size, rows, cols) != HISPMV_OK:
+        raise ValueError(lib.hispmv_prep_last_error().decode())
+    try:
+        d = (C.c_int64 * 8)()
+        lib.hispmv_prep_dims(p, d)
+        n_slices, se = int(d[4]), int(d[5])
+        words = np.ctypeslib.as_array(lib.hispmv_prep_words(p), shape=(n_slices * se,)).copy()
+        pl = (C.c_int64 * 6)()
+        lib.hispmv_prep_plan(p, int(n_cus), pl)
+        cnt = (C.c_int64 * 2)()
+        lib.hispmv_prep_apply_plan(p, int(n_cus), cnt)
+        groups = np.ctypeslib.as_array(lib.hispmv_prep_groups(p), shape=(int(cnt[0]) * 4,)).copy().reshape(-1, 4) if cnt[0] else np.zeros((0, 4), np.int32)
+        frags = np.ctypeslib.as_array(lib.hispmv_prep_frags(p), shape=(int(cnt[1]) * 4,)).copy().reshape(-1, 4) if cnt[1] else np.zeros((0, 4), np.int32)
+        dc = (C.c_int64 * 6)()
+        if lib.hispmv_prep_device_stream(p, dc) != HISPMV_OK:
+            raise ValueError(lib.hispmv_prep_last_error().decode())
+
+        def arr(which, n, dt):
+            ptr = lib.hispmv_prep_device_array(p, which)
+            return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy() if (n and ptr) else np.zeros(0, dt)
+        n_groups = int(dc[1])
+        stray_floats = int(dc[4])
+        return dict(words=words, n_slices=n_slices, threads=int(pl[0]), group_slices=int(pl[1]), window_floats=int(dc[5]), stray_floats=stray_floats,
+                    compact_slices=int(dc[2]), stray_slices=int(dc[3]), groups=groups, frags=frags, bytes=arr(0, int(dc[0]), np.uint8),
+                    dgroups=arr(1, n_groups * 4, np.int32).reshape(-1, 4),
+                    stray_cols=arr(2, n_slices * 64 if stray_floats else 0, np.uint32).reshape(-1, 64))
+    finally:
+        lib.hispmv_prep_free(p)

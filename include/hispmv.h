@@ -230,6 +230,13 @@ int hispmv_prep_window_membership(const hispmv_prep* p, int n_cus, uint8_t* insi
  * outside the window}, frags = m x {col_start, len, lds_off, 0}.  counts[0..1] = n, m. */
 int hispmv_prep_apply_plan(hispmv_prep* p, int n_cus, int64_t counts[2]);
 const int32_t* hispmv_prep_groups(const hispmv_prep* p);
+/* The planned stream in its DEVICE LAYOUT (hispmv_amd/csrc/hispmv_format.h; call hispmv_prep_apply_plan first): counts = {bytes, groups,
+ * compact slices, slices of groups with stray slots, LDS floats of the wavefronts' stray areas, LDS floats of the x window}.  Arrays:
+ * 0 = the slices, group after group (compact: 1024 x fp32 then 1024 x u16 {rowEnd:1 | LDS index:15}; wide: 1024 x u32 metas);
+ * 1 = groups x {frag_begin, frag_count, offset of the group's first slice / 2048, 1 = compact | 2 = stray slots}; 2 = slices x 64 stray
+ * columns (0xffffffff = unused; empty when no group has stray slots).  For tests: the packer without a device. */
+int hispmv_prep_device_stream(hispmv_prep* p, int64_t counts[6]);
+const void* hispmv_prep_device_array(const hispmv_prep* p, int which);
 const int32_t* hispmv_prep_frags(const hispmv_prep* p);
 
 /* Number of device / pinned-memory frees the runtime rejected since the library was loaded (a pointer released twice

@@ -362,3 +362,81 @@ def test_flavours_agree_where_their_semantics_coincide(name):
         assert P0.nnz > P1.nnz           # the mirrored (negated) off-diagonal entries
     else:
         assert P0.nnz <= P1.nnz          # loadMtx drops every value == 0, the cpu/ reader only the bit pattern 0
+
+
+def _decode_device_layout(L):
+    """The device layout of hispmv_prep_device_stream back to host words (value bits | (rowEnd << 31 | column) << 32): compact
+    metas through the group's fragment list, strays through the slice's stray columns -- checking on the way that every stray sits in
+    the stray area of the wavefront that will own the slice in the kernel's (rotated) walk."""
+    S, G, n_waves, win = 1024, L["group_slices"], L["threads"] // 64, L["window_floats"]
+    out = np.zeros(L["n_slices"] * S, dtype=np.uint64)
+    by = L["bytes"]
+    for g, (fb, fc, off_units, flags) in enumerate(L["dgroups"]):
+        s0, s1 = g * G, min(L["n_slices"], (g + 1) * G)
+        n_here = s1 - s0
+        rot = (g * 29) % n_here if n_here else 0
+        fr = L["frags"][fb:fb + fc]                         # {col_start, len, lds_off}
+        lds_off = fr[:, 2].astype(np.int64) if fc else np.zeros(0, np.int64)
+        base = int(off_units) * 2048
+        for sl in range(s0, s1):
+            compact = bool(flags & 1)
+            o = base + (sl - s0) * (6144 if compact else 8192)
+            vals = by[o:o + 4096].view(np.uint32).astype(np.uint64)
+            if compact:
+                m = by[o + 4096:o + 6144].view(np.uint16).astype(np.int64)
+                end, idx = m >> 15, m & 0x7fff
+                col = np.zeros(S, np.int64)
+                inside = idx < win
+                if inside.any():
+                    k = np.searchsorted(lds_off, idx[inside], side="right") - 1
+                    assert np.all(idx[inside] - lds_off[k] < fr[k, 1]), "window index outside its fragment"
+                    col[inside] = fr[k, 0] + (idx[inside] - lds_off[k])
+                if (~inside).any():
+                    assert flags & 2, "a stray in a group without stray slots"
+                    rel = idx[~inside] - win
+                    pos = ((sl - s0) - rot + n_here) % n_here
+                    assert np.all(rel // 64 == pos % n_waves), "stray not in the area of the wavefront that owns the slice"
+                    assert np.array_equal(rel % 64, np.arange(rel.size)), "strays of a slice are numbered in element order"
+                    sc = L["stray_cols"][sl]
+                    assert np.all(sc[rel.size:] == 0xffffffff)
+                    col[~inside] = sc[rel % 64]
+            else:
+                m = by[o + 4096:o + 8192].view(np.uint32).astype(np.int64)
+                end = m >> 31
+                low = m & 0x7fffffff
+                if fc:
+                    glob = (low & 0x40000000) != 0
+                    col = np.where(glob, low & 0x3fffffff, 0)
+                    if (~glob).any():
+                        idx = low[~glob]
+                        k = np.searchsorted(lds_off, idx, side="right") - 1
+                        col[~glob] = fr[k, 0] + (idx - lds_off[k])
+                else:
+                    col = low
+            out[sl * S:(sl + 1) * S] = vals | ((end.astype(np.uint64) << np.uint64(31) | col.astype(np.uint64)) << np.uint64(32))
+    return out
+
+
+@pytest.mark.parametrize("share", [0.0, 0.03, 0.12])
+def test_device_layout_decodes_back_to_the_host_stream(share):
+    """pack_device_stream (hispmv_plan.cpp) without a device: compact groups, groups with stray slots (3 % of the entries of a banded
+    matrix at random columns: <= 64 strays per slice) and wide groups (12 %: beyond the slots) all decode back to the host words."""
+    from hispmv_amd.prep import device_layout_from_coo
+    rng = np.random.default_rng(17)
+    rows = 400000
+    r = np.repeat(np.arange(rows, dtype=np.int64), 16)
+    c = np.clip(r + rng.integers(-1500, 1501, r.size), 0, rows - 1)
+    far = rng.random(r.size) < share
+    c[far] = rng.integers(0, rows, int(far.sum()))
+    v = rng.random(r.size, dtype=np.float32) + np.float32(0.25)
+    L = device_layout_from_coo(r.astype(np.int32), c.astype(np.int32), v, rows, rows, 256)
+    assert L["window_floats"] > 0 and L["group_slices"] > L["threads"] // 64
+    if share == 0.0:
+        assert L["stray_floats"] == 0 and L["compact_slices"] == L["n_slices"]
+    elif share == 0.03:
+        assert L["stray_floats"] == (L["threads"] // 64) * 64 and L["compact_slices"] == L["n_slices"] and L["stray_slices"] > 0.9 * L["n_slices"]
+        used = (L["stray_cols"] != 0xffffffff).sum()
+        assert 0.02 * r.size < used < 0.04 * r.size
+    else:
+        assert L["compact_slices"] < 0.2 * L["n_slices"]
+    assert np.array_equal(_decode_device_layout(L), L["words"])
