@@ -564,7 +564,8 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 if (m.parts.size() > 1) { d.lookback = false; d.use_ticket = false; }      // column tiles share one grid: fix-up launch
                 // stray slots: the packer placed every slice's strays by the slice's position in the ROTATED walk of the fix-up
                 // variant; the look-back variant walks its groups in slice order
-                if (p.dstream.stray_floats > 0) { d.lookback = false; d.use_ticket = false; }
+                d.has_strays = p.dstream.stray_floats > 0;
+                if (d.has_strays) { d.lookback = false; d.use_ticket = false; }
             }
         }
         if (!m.dense && m.parts.size() > 1) {

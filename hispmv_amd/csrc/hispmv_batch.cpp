@@ -32,7 +32,7 @@ void free_batch_plans(hispmv_ctx* c) {
 static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t n, const int32_t* idx, const float* const* d_x,
                             const float* const* bias, float* const* d_y, float beta) {
     struct Ref { int i; size_t t; };
-    struct Item { std::vector<Ref> refs; int threads; int64_t slices; };
+    struct Item { std::vector<Ref> refs; int threads; int64_t slices; bool strays = false; };      // strays: a part with stray slots (a grid class of its own)
     std::vector<Item> items;
     std::vector<Ref> refs;
     auto dev_of = [&](const Ref& r) -> SpmvDeviceMatrix& { return c->mats[idx[r.i]]->parts[r.t].dev; };
@@ -127,11 +127,12 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             for (size_t t = 0; t < m.parts.size(); ++t) { it.refs.push_back(Ref{i, t}); it.slices += m.parts[t].dev.n_slices; }
             items.push_back(std::move(it));
         } else {
-            for (size_t t = 0; t < m.parts.size(); ++t) items.push_back(Item{{Ref{i, t}}, m.parts[t].dev.block_threads, m.parts[t].dev.n_slices});
+            for (size_t t = 0; t < m.parts.size(); ++t) items.push_back(Item{{Ref{i, t}}, m.parts[t].dev.block_threads, m.parts[t].dev.n_slices, m.parts[t].dev.has_strays});
         }
     }
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) {
         if (a.threads != b.threads) return a.threads > b.threads;
+        if (a.strays != b.strays) return !a.strays;             // (parts with stray slots: their own grid, the kernel instantiation that fetches them)
         return a.slices > b.slices;
     });
     const size_t first_slice_launch = plan.launches.size();
@@ -147,7 +148,8 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         hispmv_ctx::BatchLaunch l;
         l.kind = 0;
         std::vector<MultiEntry> entries;
-        while (k < items.size() && items[k].threads == threads && entries.size() + items[k].refs.size() <= (size_t)kMultiMax) {
+        const bool strays = items[k].strays;
+        while (k < items.size() && items[k].threads == threads && items[k].strays == strays && entries.size() + items[k].refs.size() <= (size_t)kMultiMax) {
             for (const Ref& r : items[k].refs) {
                 SpmvDeviceMatrix& d = dev_of(r);
                 MultiEntry e{};

@@ -17,7 +17,8 @@ struct SpmvDeviceMatrix {
     int64_t n_groups = 0;
     int32_t group_slices = 8;           // slices per workgroup
     int32_t block_threads = 256;        // workgroup size (64 * wavefronts)
-    int32_t lds_floats = 0;             // dynamic LDS (floats) for the x window; 0 = gather x from L2
+    int32_t lds_floats = 0;             // dynamic LDS (floats) for the x window (+ the wavefronts' stray areas behind it); 0 = gather x from L2
+    bool has_strays = false;            // some groups use stray slots (hispmv_plan.h): the columns of every slice's strays follow the headers
     int32_t ytile_floats = 1024;        // LDS floats per wavefront for the row totals of one slice (>= max rows ending in a slice)
     // single-launch carry hand-off between slices (look-back); when false the fix-up kernels run instead
     bool lookback = true;

@@ -295,7 +295,7 @@ __device__ __forceinline__ void stage_fragments(const int4* __restrict__ frags, 
 
 // The work of one workgroup on group `group` of a matrix (the body of the slice kernels below), for a group stored
 // COMPACT (6 B per element) or wide (8 B): two instantiations, chosen per group by slices_body.
-template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool COMPACT>
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool COMPACT, bool STRAYS = false>
 __device__ __forceinline__ void slices_group(
     const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags,
@@ -346,7 +346,9 @@ __device__ __forceinline__ void slices_group(
     // that area, so the gathers below are plain LDS reads for every element.  Order of the requests: the columns of slice i+2
     // leave BEFORE the words of slice i+1 and the x values of slice i+1's strays BEFORE them too (vmcnt retires in issue order:
     // the wait for a slice's words then covers what that slice's turn needs, and nothing waits for anything younger).
-    const bool strays = COMPACT && (__builtin_amdgcn_readfirstlane(g.w) & 2) != 0;
+    // (STRAYS is a template parameter: matrices without stray slots run instantiations that carry none of this -- with it in, the
+    // multi-matrix kernel went from 91 to 97 VGPRs, four wavefronts per SIMD instead of five, and the step lost 0.4 %)
+    const bool strays = STRAYS && COMPACT && (__builtin_amdgcn_readfirstlane(g.w) & 2) != 0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(hdr + n_slices), 0, strays ? (int)(n_slices * (kStraySlots * 4)) : 0, 0x00020000);
     float* const stray_area = xs + (lds_floats - n_waves * kStraySlots) + wave * kStraySlots;
     unsigned sc_next = 0xffffffffu;        // stray columns of this wavefront's NEXT slice
@@ -631,7 +633,7 @@ __device__ __forceinline__ void slices_group(
     }
 }
 
-template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool STRAYS = false>
 __device__ __forceinline__ void slices_body(
     const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
@@ -655,7 +657,7 @@ __device__ __forceinline__ void slices_body(
     if constexpr (USE_LDS) {
         const int4 g = load_int4(groups + group);     // {first fragment, fragments, offset of the group's slices, compact}
         if (__builtin_amdgcn_readfirstlane(g.w) != 0)
-            slices_group<HAS_BETA, true, LOOKBACK, true>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+            slices_group<HAS_BETA, true, LOOKBACK, true, STRAYS>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
                                                          lds_floats, ytile_floats, cols, rows, lb, group, g);
         else
             slices_group<HAS_BETA, true, LOOKBACK, false>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
@@ -666,13 +668,13 @@ __device__ __forceinline__ void slices_body(
     }
 }
 
-template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK>
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool STRAYS = false>
 __global__ __launch_bounds__(1024) void spmv_slices_kernel(
     const char* __restrict__ words, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
     int lds_floats, int ytile_floats, int cols, int rows, LookbackArgs lb) {
-    slices_body<HAS_BETA, USE_LDS, LOOKBACK>(words, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+    slices_body<HAS_BETA, USE_LDS, LOOKBACK, STRAYS>(words, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
                                              lds_floats, ytile_floats, cols, rows, lb, (long long)blockIdx.x);
 }
 
@@ -683,7 +685,8 @@ __global__ __launch_bounds__(1024) void spmv_slices_kernel(
 // SpMVs -- the 20 matrices of the benchmark set, the heads of a model -- then share launch ramps and tails instead of
 // paying 6-20 us of launch latency each.  All matrices of a launch have the same workgroup size.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
+template <bool STRAYS>
+__global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
     int k = 0;
 #pragma unroll 1
     while (k + 1 < prefix.n && (long long)blockIdx.x >= prefix.begin[k + 1]) ++k;
@@ -701,10 +704,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
     // beta is per entry: the first column tile of a matrix applies beta*bias, its other tiles write alpha*A_t*x into the
     // handle's partial vectors (no bias read) -- both kinds share the grid, a workgroup runs one of the two bodies
     if (t.beta != 0.0f)
-        slices_body<true, true, false>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, t.beta,
+        slices_body<true, true, false, STRAYS>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, alpha, t.beta,
                                        t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
     else
-        slices_body<false, true, false>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, alpha, 0.0f,
+        slices_body<false, true, false, STRAYS>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, alpha, 0.0f,
                                         t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
 }
 
@@ -1025,6 +1028,11 @@ static void launch_slices(const SpmvDeviceMatrix& m, const LookbackArgs& lb, con
                           float alpha, float beta, hipStream_t stream) {
     const size_t lds = ((USE_LDS ? (size_t)m.lds_floats : 0) + (size_t)m.ytile_floats * (m.block_threads / 64)) * sizeof(float) +
                        (LOOKBACK ? (size_t)m.group_slices * 8 : 0);
+    if (USE_LDS && !LOOKBACK && m.has_strays)       // (stray slots: the instantiation that fetches them; never with look-back, hispmv_abi.cpp)
+        hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS && !LOOKBACK, false, USE_LDS && !LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
+                           (const char*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
+                           (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, lb);
+    else
     hipLaunchKernelGGL((spmv_slices_kernel<HAS_BETA, USE_LDS, LOOKBACK>), dim3((unsigned)m.n_groups), dim3(m.block_threads), lds, stream,
                        (const char*)m.words, m.hdr, m.groups, m.frags, x, bias, y, m.carry, alpha, beta,
                        (long long)m.n_slices, m.group_slices, m.lds_floats, m.ytile_floats, m.cols, m.rows, lb);
@@ -1049,6 +1057,8 @@ hipError_t prepare_spmv_kernels() {
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)spmv_slices_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -1178,10 +1188,14 @@ hipError_t launch_spmv_multi(const SpmvDeviceMatrix* const* parts, int n, const 
     static bool raised = false;
     if (!raised) {
         hipError_t err;
-        if ((err = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return err;
+        if ((err = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return err;
+        if ((err = hipFuncSetAttribute((const void*)spmv_slices_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return err;
         raised = true;
     }
-    if (g > 0) hipLaunchKernelGGL(spmv_slices_multi_kernel, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha);
+    bool strays = false;          // (a launch with a stray-slot part takes the instantiation that fetches them; hispmv_batch.cpp keeps such parts in grids of their own)
+    for (int i = 0; i < n; ++i) strays = strays || parts[i]->has_strays;
+    if (g > 0 && strays) hipLaunchKernelGGL(spmv_slices_multi_kernel<true>, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha);
+    else if (g > 0) hipLaunchKernelGGL(spmv_slices_multi_kernel<false>, dim3((unsigned)g), dim3(threads), lds, stream, d_table, px, alpha);
     return hipGetLastError();
 }
 
@@ -1852,7 +1866,7 @@ hipError_t graph_set_alpha(hipGraphExec_t exec, hipGraph_t graph, float alpha) {
         hipKernelNodeParams p{};
         if ((e = hipGraphKernelNodeGetParams(nodes[i], &p)) != hipSuccess) return e;
         int idx, n_args;
-        if (p.func == (void*)spmv_slices_multi_kernel || p.func == (void*)spmv_tts_multi_kernel<false> || p.func == (void*)spmv_tts_multi_kernel<true> ||
+        if (p.func == (void*)spmv_slices_multi_kernel<false> || p.func == (void*)spmv_slices_multi_kernel<true> || p.func == (void*)spmv_tts_multi_kernel<false> || p.func == (void*)spmv_tts_multi_kernel<true> ||
             p.func == (void*)spmv_tts_multi_kernel<false, true> ||
             p.func == (void*)gemv_rows_multi_kernel ||
             p.func == (void*)spmv_fixup_multi_kernel) { idx = 2; n_args = 3; }
