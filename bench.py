@@ -300,6 +300,7 @@ class Runner:
         torch.cuda.set_stream(self.stream)
         self.sptr = self.stream.cuda_stream
         assert self.sptr != 0
+        self.passes = 0            # passes over the workload issued so far (every step of every phase: what a profiler sees)
 
     def add(self, mats):
         """Creates the handles (sparse from CSR / file, dense from an array), loads them, attaches device vectors."""
@@ -340,6 +341,7 @@ class Runner:
             exch.prepare(mats)
 
             def step():
+                self.passes += 1
                 fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
                 exch.run(mats, ALPHA, prepared=True)
             # The rank's whole step -- batch launches, tail pack, the RCCL all_gather, tail apply -- as ONE graph launch: the
@@ -360,7 +362,11 @@ class Runner:
                     self.fence()
                     self.step_graph = g                 # (keeps the graph alive)
                     self.step_mode = "graph"
-                    return g.replay
+
+                    def replay():
+                        self.passes += 1
+                        g.replay()
+                    return replay
                 except Exception as ex:                 # capture refused: eager step
                     sys.stderr.write(f"bench.py: step graph not used ({type(ex).__name__}: {str(ex)[:200]})\n")
                     try:
@@ -370,6 +376,7 @@ class Runner:
                     self.step_mode = "eager"
         else:
             def step():
+                self.passes += 1
                 fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
         return step
 
@@ -682,6 +689,7 @@ def main():
         for k in range(reps + 3):
             e = evs[max(0, k - 3)]
             e[0].record(stream)
+            R.passes += 1
             fpga.spmv_device_batch(batch, ALPHA, BETA, sptr)
             e[1].record(stream)
             if exch_ is not None:
@@ -709,6 +717,7 @@ def main():
         return summarize_ranks(allr)
 
     breakdown = rank_breakdown(mats, exch) if args.launch == "batch" else None
+    passes_main = R.passes + (args.warmup + args.steps + 2 if args.launch == "streams" else 0)      # before the sub-measurements add theirs
 
     def alg_bytes(m):
         if m.get("dense") is not None:
@@ -872,7 +881,9 @@ def main():
                        "alpha": ALPHA, "beta": BETA, "launch": args.launch, "streams": n_streams,
                        "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
             "ranks_seen": ranks_seen, "backend": backend, "rank_step": getattr(R, "step_mode", "eager" if dist_on else "library graph"),
-            "passes_over_set": args.warmup + args.steps + (2 if args.launch == "streams" else 0),
+            # every pass over the workload this process issued for the MAIN measurement -- preheat, warm-up, timed steps, the
+            # self-check's step, the rank breakdown's eager steps: what a profiler divides its per-kernel totals by
+            "passes_over_set": passes_main,
             "hbm_gbs_algorithmic": round(total_bytes / t_wall / 1e9, 1),
             "hbm_pct_of_peak": round(100 * total_bytes / t_wall / 1e9 / (HBM_PEAK_GBS * world), 2),
             "geomean_gflops_per_matrix": None if geo is None else round(geo, 2),

@@ -455,11 +455,21 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
             if ((rc = upload(c, m, ts.words.data(), ts.words.size(), &dw)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, ts.col_base.data(), ts.col_base.size(), &dcb)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, ts.flags.data(), ts.flags.size(), &dfl)) != HISPMV_OK) return rc;
+            const uint16_t* dfh = nullptr;
+            std::vector<uint32_t> planes;          // gap-coded row ends: both planes of the codes in one word per lane and chunk
+            if (!ts.flags_hi.empty()) {
+                planes.resize(ts.flags.size());
+                for (size_t q = 0; q < planes.size(); ++q) planes[q] = (uint32_t)ts.flags[q] | ((uint32_t)ts.flags_hi[q] << 16);
+                const uint32_t* dp = nullptr;
+                if ((rc = upload(c, m, planes.data(), planes.size(), &dp)) != HISPMV_OK) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));      // (`planes` is a local)
+                dfh = (const uint16_t*)dp;
+            }
             if ((rc = upload(c, m, ts.chunk_info.data(), ts.chunk_info.size(), &dci)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, ts.tiles.data(), ts.tiles.size(), &dt)) != HISPMV_OK) return rc;
             if ((rc = upload(c, m, ts.blocks.data(), ts.blocks.size(), &db)) != HISPMV_OK) return rc;
             TtsDeviceMatrix& d = p.tdev;
-            d.words = dw; d.col_base = dcb; d.flags = dfl; d.chunk_info = (const int2*)dci; d.tiles = (const int4*)dt; d.blocks = (const int4*)db;
+            d.words = dw; d.col_base = dcb; d.flags = dfl; d.flags_hi = dfh; d.chunk_info = (const int2*)dci; d.tiles = (const int4*)dt; d.blocks = (const int4*)db;
             d.n_tiles = (int32_t)ts.tiles.size(); d.rows = m.rows; d.cols = m.cols;
             if (!ts.fix.empty()) {       // rows cut into pieces: carry slots + the slice stream's fix-up entries
                 const int32_t* dfix = nullptr;
@@ -474,7 +484,7 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 p.dev.fix_short = d.fix; p.dev.n_fix_short = d.n_fix; p.dev.carry = d.carry; p.dev.n_fix_long = 0;
             }
             d.acc_floats = (ts.max_rows + 63) & ~63; d.threads = ts.geometry.threads;
-            d.zero_fill = ts.geometry.zero_fill ? 1 : 0;
+            d.zero_fill = ts.geometry.zero_fill ? 1 : ts.geometry.gap_rows ? 2 : 0;
             d.staging_floats = ts.geometry.max_slots + 64;        // (the dummy slot of padding words sits behind the last real one)
             d.batch_stage_floats = ((ts.max_slots + kTtsChunk - 1) / kTtsChunk) * kTtsChunk + 64;
             // x in the LDS for short x (HISPMV_TTS_XLDS=1; off by default -- measured slower on the 1024 x 8192 layer of

@@ -70,7 +70,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
     }
     // (+ 1 << 24: matrices whose x the kernel keeps in the LDS -- another LDS size, another kernel instantiation)
     auto tts_class = [](const Matrix& m) {
-        return m.parts[0].tdev.staging_floats + (m.parts.size() == 1 && tts_x_in_lds(m.parts[0].tdev, 1) ? (1 << 24) : 0) + (m.parts[0].tdev.zero_fill ? (1 << 25) : 0);
+        return m.parts[0].tdev.staging_floats + (m.parts.size() == 1 && tts_x_in_lds(m.parts[0].tdev, 1) ? (1 << 24) : 0) + (m.parts[0].tdev.zero_fill << 25);
     };
     std::vector<int> tts_classes;                // staging size = the geometry (hispmv_tts.h): small 13 K, standard 28 K, tall 23 K, paired 11 K
     for (int i = 0; i < n; ++i) {

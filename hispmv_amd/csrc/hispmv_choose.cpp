@@ -14,7 +14,7 @@ FormatOptions FormatOptions::from_env() {
     if (const char* e = std::getenv("HISPMV_BAND_TILES")) o.band_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("HISPMV_STRAY_SPLIT")) o.stray_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("HISPMV_TTS_GEOMETRY"))
-        o.tts_geometry = !std::strcmp(e, "standard") ? 0 : !std::strcmp(e, "tall") ? 1 : !std::strcmp(e, "paired") ? 3 : !std::strcmp(e, "zerofill") ? 4 : 2;
+        o.tts_geometry = !std::strcmp(e, "standard") ? 0 : !std::strcmp(e, "tall") ? 1 : !std::strcmp(e, "paired") ? 3 : !std::strcmp(e, "zerofill") ? 4 : !std::strcmp(e, "tallgap") ? 5 : 2;
     if (const char* e = std::getenv("HISPMV_COL_TILE_BYTES")) o.col_tile_bytes = std::atoll(e);
     if (const char* e = std::getenv("HISPMV_TTS_MIN_NNZ")) o.tts_min_nnz = std::atoll(e);
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
@@ -334,7 +334,8 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
             // pay for fewer lines with 46 % more row-order slots -- DESIGN.md 2.2).
             std::vector<TtsStream> tall;
             const bool paired = opt.tts_geometry == 3;
-            const bool want_tall = opt.tts_geometry == 1 || paired ||
+            const bool tallgap = opt.tts_geometry == 5;
+            const bool want_tall = opt.tts_geometry == 1 || paired || tallgap ||
                                    (opt.tts_geometry == 2 && ts.lines_per_gather > 16.0 && (int64_t)used * 4 > (4 << 20) && csr.rows >= 64 * kTtsTallRows);
             if (want_tall) {
                 const std::vector<int32_t> cuts = tts_column_cuts(csr, kTtsTallParts);
@@ -342,7 +343,7 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
                 bool ok = true;
                 for (int q = 0; q < kTtsTallParts && ok; ++q) {
                     Csr part = csr_column_range(csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? csr.cols : cuts[(size_t)q]);
-                    tall.push_back(build_tts(part, 0, paired ? tts_paired_geometry(n_cus) : tts_tall_geometry(n_cus, kTtsTallParts)));
+                    tall.push_back(build_tts(part, 0, tallgap ? tts_tallgap_geometry(n_cus, kTtsTallParts) : paired ? tts_paired_geometry(n_cus) : tts_tall_geometry(n_cus, kTtsTallParts)));
                     const TtsStream& t = tall.back();
                     lines += t.lines_per_gather * (double)t.col_base.size(); slices += (int64_t)t.col_base.size();
                     ok = t.max_tile_slots <= 2 * (t.total_slots / std::max<int64_t>(1, (int64_t)t.tiles.size())) + 4096;

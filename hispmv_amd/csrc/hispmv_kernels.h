@@ -38,13 +38,16 @@ struct TtsDeviceMatrix {
     const void* words = nullptr;        // per column-order slice: 1024 x fp32, then 1024 x {col_off:16 | slot:16}
     const int32_t* col_base = nullptr;  // per slice
     const uint16_t* flags = nullptr;    // per row-major chunk: 64 x u16 row-end bits
+    const uint16_t* flags_hi = nullptr; // gap-coded row ends (TtsGeometry::gap_rows): BOTH planes interleaved, one u32 per lane and chunk (bit 0 of the codes in
+                                        // the lower half, bit 1 in the upper half) -- the kernel reads this array instead of `flags`; NULL otherwise
     const int2* chunk_info = nullptr;   // per chunk: {rows ending before it, chain_len}
     const int4* tiles = nullptr;        // {row0, n_rows, block_begin, n_blocks}; row0 < 0: carry tile, its sum -> carry[-row0 - 1]
     const int4* blocks = nullptr;       // 2 x int4 per block: {slice_begin, n_slices, chunk_begin, n_chunks}, {n_slots, 0, 0, 0}
     float* carry = nullptr;             // raw sums of the carry tiles (pieces of rows longer than two tiles)
     const int4* fix = nullptr;          // {row, first carry, carries, 0} per such row: y[row] += alpha * sum (spmv_fixup_short_kernel)
     int32_t n_fix = 0;
-    int32_t zero_fill = 0;              // 1: rows absent from a block have no stream word, the staging is kept zero-filled (TtsGeometry::zero_fill)
+    int32_t zero_fill = 0;              // 1: rows absent from a block have no stream word, the staging is kept zero-filled (TtsGeometry::zero_fill);
+                                        // 2: gap-coded row ends (TtsGeometry::gap_rows): absent rows own nothing, a row end's accumulator = running sum of the codes
     int32_t n_tiles = 0, rows = 0, cols = 0;
     int32_t n_carry = 0;                // carry tiles; the carry buffer holds kTtsMaxVectors x n_carry (vector v of a batched launch: carry + v * n_carry)
     int32_t acc_floats = 0, staging_floats = 0;    // LDS: accumulators (max rows of a tile), staging (max slots of a block + dummy)

@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void tts_request(TtsSlice& s, const char* words, int 
 // staging: the workgroup copies it there once (coalesced) and phase A gathers with ds_read_b32 -- the vector cache takes the
 // lanes of a scattered global gather one per cycle or two, the LDS 32 per cycle.  The wide, short layers of
 // apps/model_test.py (1024 x 8192).  Staging areas are sized by the matrix's largest block (batch_stage_floats), as for NV > 1.
-template <bool HAS_BETA, bool ZERO_FILL = false, int NV = 1, bool XLDS = false>
+template <bool HAS_BETA, bool ZERO_FILL = false, int NV = 1, bool XLDS = false, bool GAP = false>
 __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const float* __restrict__ x, const float* bias, float* y,
                                               float alpha, float beta, int tile_index) {
     extern __shared__ float xs[];
@@ -1403,6 +1403,9 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         }
     };
     // phase B for one chunk of 1024 staged products in row-major order
+    // GAP (TtsGeometry::gap_rows): a row end carries a 2-bit code = distance to the previous slot-owning row (`ends` bit 0, `ends_hi`
+    // bit 1); its accumulator is ci.x + the running SUM of the codes, instead of ci.x + the running count of row ends
+    // (GAP: `ends` holds both planes, bit 1 of the codes in its upper half -- one register, one load: M.flags_hi is the interleaved array)
     auto phase_b = [&](int c, int2 ci, unsigned ends) {
 #pragma unroll 1
         for (int v = 0; v < NV; ++v) {
@@ -1416,13 +1419,23 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
             if (ZERO_FILL) ((float4*)st4)[j * 64] = float4{0.0f, 0.0f, 0.0f, 0.0f};
             const float pj[kLaneElems] = {q.x, q.y, q.z, q.w};
             bool e[kLaneElems];
+            int code[kLaneElems];          // GAP: 1..3 at a row end, 0 elsewhere
             int below = 0, total = 0;
 #pragma unroll
             for (int k = 0; k < kLaneElems; ++k) {
-                e[k] = ((ends >> (4 * j + k)) & 1u) != 0;
-                const unsigned long long mk = __builtin_amdgcn_ballot_w64(e[k]);
-                below += lanes_below(mk);
-                total += __builtin_popcountll(mk);
+                if (GAP) {
+                    const bool lo = ((ends >> (4 * j + k)) & 1u) != 0, hi = ((ends >> (16 + 4 * j + k)) & 1u) != 0;
+                    e[k] = lo | hi;
+                    code[k] = (lo ? 1 : 0) + (hi ? 2 : 0);
+                    const unsigned long long ml = __builtin_amdgcn_ballot_w64(lo), mh = __builtin_amdgcn_ballot_w64(hi);
+                    below += lanes_below(ml) + 2 * lanes_below(mh);
+                    total += __builtin_popcountll(ml) + 2 * __builtin_popcountll(mh);
+                } else {
+                    e[k] = ((ends >> (4 * j + k)) & 1u) != 0;
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(e[k]);
+                    below += lanes_below(mk);
+                    total += __builtin_popcountll(mk);
+                }
             }
             float tj[kLaneElems];
             scan_step(pj, e[0], e[1], e[2], e[3], carry_step, tj);
@@ -1430,9 +1443,15 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
             // are independent -- all reads, then all writes, one LDS round trip instead of four
             int r[kLaneElems];
             float a[kLaneElems];
+            if (GAP) {
+                r[0] = row + below + code[0];
+#pragma unroll
+                for (int k = 1; k < kLaneElems; ++k) r[k] = r[k - 1] + code[k];
+            } else {
             r[0] = row + below;
 #pragma unroll
             for (int k = 1; k < kLaneElems; ++k) r[k] = r[k - 1] + (e[k - 1] ? 1 : 0);
+            }
 #pragma unroll
             for (int k = 0; k < kLaneElems; ++k) a[k] = e[k] ? acc[r[k]] : 0.0f;
 #pragma unroll
@@ -1454,13 +1473,17 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         // loads counting in order, the arrival of the next block's slices as well)
         int2 ciA = int2{0, 0}, ciB = int2{0, 0}, ciT = int2{0, 0};
         unsigned endsA = 0, endsB = 0;
+        auto load_ends = [&](int c) -> unsigned {
+            if (GAP) return *(const HISPMV_GLOBAL unsigned*)((const unsigned*)M.flags_hi + (size_t)(chunk_begin + c) * 64 + lane);
+            return *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + c) * 64 + lane);
+        };
         if (wave < n_chunks) {
             ciA = load_int2(M.chunk_info + chunk_begin + wave_u);
-            endsA = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + wave) * 64 + lane);
+            endsA = load_ends(wave);
         }
         if (wave + n_waves < n_chunks) {
             ciB = load_int2(M.chunk_info + chunk_begin + wave_u + n_waves);
-            endsB = *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + wave + n_waves) * 64 + lane);
+            endsB = load_ends(wave + n_waves);
         }
         if (wave == 0 && lane < n_chunks) ciT = load_int2(M.chunk_info + chunk_begin + lane);
         // ---- phase A: column order --------------------------------------------------------------------------------
@@ -1480,7 +1503,7 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         if (wave < n_chunks) phase_b(wave, ciA, endsA);
         if (wave + n_waves < n_chunks) phase_b(wave + n_waves, ciB, endsB);
         for (int c = wave + 2 * n_waves; c < n_chunks; c += n_waves)
-            phase_b(c, load_int2(M.chunk_info + chunk_begin + c), *(const HISPMV_GLOBAL unsigned short*)(M.flags + (size_t)(chunk_begin + c) * 64 + lane));
+            phase_b(c, load_int2(M.chunk_info + chunk_begin + c), load_ends(c));
 #else
         (void)endsA; (void)endsB; (void)ciA; (void)ciB;
 #endif
@@ -1488,13 +1511,16 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         // rows cut by a chunk boundary: the chunk that holds the row end added its own part; the tails of the chunks
         // before it follow here, in chunk order (one lane per chunk; a block has at most 48 chunks)
         if (wave == 0 && lane < n_chunks) {
-            if (ciT.y > 0) {
+            // (GAP: chunk_info = {last slot-owning row before the chunk, chain | code of the chunk's first row end << 16})
+            const int t_chain = GAP ? (ciT.y & 0xffff) : ciT.y;
+            const int t_row = GAP ? ciT.x + (ciT.y >> 16) : ciT.x;
+            if (t_chain > 0) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     float* const acc = acc0 + v * M.acc_floats;
                     float s = 0.0f;
-                    for (int k = lane - ciT.y; k < lane; ++k) s += tails[v * 64 + k];
-                    acc[ciT.x] = acc[ciT.x] + s;
+                    for (int k = lane - t_chain; k < lane; ++k) s += tails[v * 64 + k];
+                    acc[t_row] = acc[t_row] + s;
                 }
             }
         }
@@ -1549,7 +1575,7 @@ __global__ __launch_bounds__(1024) void spmv_tts_batched_kernel(TtsDeviceMatrix 
     }
 }
 
-template <bool ZERO_FILL, bool XLDS = false>
+template <bool ZERO_FILL, bool XLDS = false, bool GAP = false>
 __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __restrict__ table, MultiPrefix prefix, float alpha) {
     int k = 0;
 #pragma unroll 1
@@ -1567,8 +1593,8 @@ __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __
     }
     const TtsEntry e = table[entry];      // (once per workgroup; every load in the body is cast to the global address space)
     if (tile >= e.m.n_tiles) return;      // (a part with fewer tiles than its sibling)
-    if (e.beta != 0.0f) tts_tile_body<true, ZERO_FILL, 1, XLDS>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
-    else tts_tile_body<false, ZERO_FILL, 1, XLDS>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
+    if (e.beta != 0.0f) tts_tile_body<true, ZERO_FILL, 1, XLDS, GAP>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
+    else tts_tile_body<false, ZERO_FILL, 1, XLDS, GAP>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
 }
 
 template <int NV, bool XLDS>
@@ -1678,6 +1704,7 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
         if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_tts_multi_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
         raised = true;
     }
     if (!item_parts) n_items = n;
@@ -1706,6 +1733,7 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
     if (g > 0x7fffffffLL || lds > 160 * 1024 - 256) return hipErrorInvalidValue;
     for (int i = 1; i < n; ++i) if (entries[i].m.zero_fill != entries[0].m.zero_fill || entries[i].m.threads != entries[0].m.threads) return hipErrorInvalidValue;
     if (g > 0 && xlds) hipLaunchKernelGGL((spmv_tts_multi_kernel<false, true>), dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
+    else if (g > 0 && entries[0].m.zero_fill == 2) hipLaunchKernelGGL((spmv_tts_multi_kernel<false, false, true>), dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     else if (g > 0 && entries[0].m.zero_fill) hipLaunchKernelGGL(spmv_tts_multi_kernel<true>, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     else if (g > 0) hipLaunchKernelGGL(spmv_tts_multi_kernel<false>, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     return hipGetLastError();
@@ -1867,7 +1895,7 @@ hipError_t graph_set_alpha(hipGraphExec_t exec, hipGraph_t graph, float alpha) {
         if ((e = hipGraphKernelNodeGetParams(nodes[i], &p)) != hipSuccess) return e;
         int idx, n_args;
         if (p.func == (void*)spmv_slices_multi_kernel<false> || p.func == (void*)spmv_slices_multi_kernel<true> || p.func == (void*)spmv_tts_multi_kernel<false> || p.func == (void*)spmv_tts_multi_kernel<true> ||
-            p.func == (void*)spmv_tts_multi_kernel<false, true> ||
+            p.func == (void*)spmv_tts_multi_kernel<false, true> || p.func == (void*)spmv_tts_multi_kernel<false, false, true> ||
             p.func == (void*)gemv_rows_multi_kernel ||
             p.func == (void*)spmv_fixup_multi_kernel) { idx = 2; n_args = 3; }
         else if (p.func == (void*)spmv_fixup_long_kernel) { idx = 4; n_args = 7; }

@@ -158,13 +158,13 @@ HISPMV_API int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, 
         TtsGeometry geo;
         if (small_geometry == 1) { geo.max_slots = kTtsSmallSlots; geo.max_rows = kTtsSmallRows; geo.tiles_wanted = 512; }
         if (small_geometry == 6) geo.zero_fill = true;      // the standard sizes without filler words (HISPMV_TTS_GEOMETRY=zerofill)
-        if (small_geometry >= 2 && small_geometry < 6) {         // 2 + q / 4 + q: column part q of the tall / paired geometry, as the loader builds it for a 256-CU device
-            const bool paired = small_geometry >= 4;
-            const int q = small_geometry - (paired ? 4 : 2);
+        if ((small_geometry >= 2 && small_geometry < 6) || small_geometry == 8 || small_geometry == 9) {         // 2 + q / 4 + q / 8 + q: column part q of the tall / paired / tall gap-coded geometry, as the loader builds it for a 256-CU device
+            const bool paired = small_geometry >= 4 && small_geometry < 6, gap = small_geometry >= 8;
+            const int q = small_geometry - (gap ? 8 : paired ? 4 : 2);
             if (q >= kTtsTallParts) { g_prep_err = "no such column part"; return HISPMV_EINVAL; }
             const std::vector<int32_t> cuts = tts_column_cuts(p->csr, kTtsTallParts);
             const Csr part = csr_column_range(p->csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? p->csr.cols : cuts[(size_t)q]);
-            p->tts = build_tts(part, target_tile_elems, paired ? tts_paired_geometry(256) : tts_tall_geometry(256, kTtsTallParts));
+            p->tts = build_tts(part, target_tile_elems, gap ? tts_tallgap_geometry(256, kTtsTallParts) : paired ? tts_paired_geometry(256) : tts_tall_geometry(256, kTtsTallParts));
         } else
         p->tts = build_tts(p->csr, target_tile_elems, geo);
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
@@ -183,6 +183,7 @@ HISPMV_API const void* hispmv_prep_tts_array(const hispmv_prep* p, int which) {
     if (!p) return nullptr;
     switch (which) {
         case 6: return p->tts.fix.data();
+        case 7: return p->tts.flags_hi.data();
         case 0: return p->tts.words.data();
         case 1: return p->tts.col_base.data();
         case 2: return p->tts.flags.data();

@@ -14,7 +14,7 @@ struct TileOut {
     std::vector<TtsBlock> blocks;            // slice_begin / chunk_begin relative to the tile
     std::vector<uint8_t> words;
     std::vector<int32_t> col_base;
-    std::vector<uint16_t> flags;
+    std::vector<uint16_t> flags, flags_hi;
     std::vector<int32_t> chunk_info;
     int64_t fillers = 0, pads = 0;
     double lines = 0; int64_t gathers = 0;
@@ -27,11 +27,26 @@ struct Elem { int32_t col; int32_t row; float val; };     // row: tile-local
 void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, TileOut& out, std::vector<int32_t>& cnt,
                 std::vector<int32_t>& start, std::vector<uint32_t>& slot_of, const TtsGeometry& geo) {
     // row-major order of the block: rows ascending, inside a row the elements in column order (the order of `el`), a row
-    // without elements in this block gets one filler slot
+    // without elements in this block gets one filler slot -- or, with gap-coded row ends, nothing at all unless it has to break
+    // a run of absent rows (a row end's code reaches at most 3 rows back)
     std::fill(cnt.begin(), cnt.begin() + n_rows, 0);
     for (size_t i = e0; i < e1; ++i) cnt[(size_t)el[i].row]++;
     int32_t pos = 0, fillers = 0;
-    for (int r = 0; r < n_rows; ++r) { start[(size_t)r] = pos; if (cnt[(size_t)r] == 0) { ++fillers; pos += 1; } else pos += cnt[(size_t)r]; }
+    std::vector<uint8_t> owns((size_t)n_rows, 1), code((size_t)n_rows, 1);      // gap_rows: which rows own a slot, and their codes
+    if (geo.gap_rows) {
+        int prev = -1;
+        for (int r = 0; r < n_rows; ++r) {
+            const bool present = cnt[(size_t)r] > 0;
+            const bool breaker = !present && r - prev == 3;         // third absent row in a run: a filler keeps the next code <= 3
+            owns[(size_t)r] = present || breaker;
+            if (owns[(size_t)r]) { code[(size_t)r] = (uint8_t)(r - prev); prev = r; }
+        }
+    }
+    for (int r = 0; r < n_rows; ++r) {
+        start[(size_t)r] = pos;
+        if (!owns[(size_t)r]) continue;
+        if (cnt[(size_t)r] == 0) { ++fillers; pos += 1; } else pos += cnt[(size_t)r];
+    }
     const int32_t n_slots = pos;
     if (n_slots > geo.max_slots) throw std::logic_error("internal: TTS block exceeds its slot budget");
     const int32_t n_chunks = (n_slots + kTtsChunk - 1) / kTtsChunk;
@@ -42,22 +57,37 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
     // row-end flags and chunk table
     const size_t f0 = out.flags.size();
     out.flags.resize(f0 + (size_t)n_chunks * 64, 0);
+    if (geo.gap_rows) out.flags_hi.resize(f0 + (size_t)n_chunks * 64, 0);
     std::vector<int32_t> ends_before((size_t)n_chunks + 1, 0);
-    auto set_end = [&](int32_t slot) {
+    std::vector<int32_t> first_row((size_t)n_chunks, -1), last_before((size_t)n_chunks + 1, -1);      // gap_rows: first row ending in / last row ending before a chunk
+    auto set_end = [&](int32_t slot, int r) {
         const int32_t c = slot / kTtsChunk, s = slot % kTtsChunk;
         const int j = s / 256, l = (s % 256) / 4, k = s % 4;
-        out.flags[f0 + (size_t)c * 64 + (size_t)l] |= (uint16_t)(1u << (4 * j + k));
+        const int cd = geo.gap_rows ? code[(size_t)r] : 1;
+        if (cd & 1) out.flags[f0 + (size_t)c * 64 + (size_t)l] |= (uint16_t)(1u << (4 * j + k));
+        if (cd & 2) out.flags_hi[f0 + (size_t)c * 64 + (size_t)l] |= (uint16_t)(1u << (4 * j + k));
         ends_before[(size_t)c + 1]++;
+        if (first_row[(size_t)c] < 0) first_row[(size_t)c] = r;
+        last_before[(size_t)c + 1] = r;
     };
-    for (int r = 0; r < n_rows; ++r) set_end(start[(size_t)r] + std::max(cnt[(size_t)r], 1) - 1);
+    for (int r = 0; r < n_rows; ++r) if (owns[(size_t)r]) set_end(start[(size_t)r] + std::max(cnt[(size_t)r], 1) - 1, r);
     for (int c = 0; c < n_chunks; ++c) ends_before[(size_t)c + 1] += ends_before[(size_t)c];
+    for (int c = 0; c < n_chunks; ++c) if (last_before[(size_t)c + 1] < 0) last_before[(size_t)c + 1] = last_before[(size_t)c];
     for (int c = 0; c < n_chunks; ++c) {
-        const int32_t row_base = ends_before[(size_t)c];        // first row that ends in this chunk (when one does)
-        int32_t chain = 0;
-        if (ends_before[(size_t)c + 1] > row_base && row_base < n_rows && start[(size_t)row_base] < c * kTtsChunk)
-            chain = c - start[(size_t)row_base] / kTtsChunk;
-        out.chunk_info.push_back(row_base);
-        out.chunk_info.push_back(chain);
+        if (!geo.gap_rows) {
+            const int32_t row_base = ends_before[(size_t)c];        // first row that ends in this chunk (when one does)
+            int32_t chain = 0;
+            if (ends_before[(size_t)c + 1] > row_base && row_base < n_rows && start[(size_t)row_base] < c * kTtsChunk)
+                chain = c - start[(size_t)row_base] / kTtsChunk;
+            out.chunk_info.push_back(row_base);
+            out.chunk_info.push_back(chain);
+        } else {
+            const int32_t fr = first_row[(size_t)c];               // first row that ends in this chunk (-1: none)
+            int32_t chain = 0;
+            if (fr >= 0 && start[(size_t)fr] < c * kTtsChunk) chain = c - start[(size_t)fr] / kTtsChunk;
+            out.chunk_info.push_back(last_before[(size_t)c]);      // the last slot-owning row before the chunk: row ends add their codes to it
+            out.chunk_info.push_back(chain | ((fr >= 0 ? (int32_t)code[(size_t)fr] : 0) << 16));
+        }
     }
     // slots of the elements (column order -> row-major position); cnt[] becomes the running fill of each row
     std::fill(cnt.begin(), cnt.begin() + n_rows, 0);
@@ -74,7 +104,7 @@ void pack_block(const std::vector<Elem>& el, size_t e0, size_t e1, int n_rows, T
     // slice it lands in" (offset 0: a valid column, the gather is a broadcast)
     // (zero_fill geometry: nothing is streamed for an absent row -- its slot of the zero-filled staging reads 0.0)
     if (!geo.zero_fill)
-        for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0) ws.push_back(W{-1, (uint32_t)start[(size_t)r], 0.0f});
+        for (int r = 0; r < n_rows; ++r) if (cnt[(size_t)r] == 0 && owns[(size_t)r]) ws.push_back(W{-1, (uint32_t)start[(size_t)r], 0.0f});
     size_t i = 0;
     while (i < ws.size()) {
         const int32_t base = (ws[i].col >= 0 ? ws[i].col : first_col) & ~31;          // 128-byte aligned
@@ -212,7 +242,8 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
                     // the element opens a new slice when the open one is full or its 16-bit column offset would overflow
                     if (sl_count == 0 || sl_fill == kTtsChunk || el[i].col - sl_base >= 65536) { n_sl = sl_count + 1; n_fill = 1; n_base = el[i].col & ~31; }
                     else n_fill = sl_fill + 1;
-                    const int64_t fillers = n_rows - distinct - add_distinct;
+                    // (gap-coded row ends: at most every third absent row needs a filler)
+                    const int64_t fillers = geo.gap_rows ? (n_rows - distinct - add_distinct + 2) / 3 : n_rows - distinct - add_distinct;
                     const int64_t extra = geo.zero_fill ? 0 : fillers - (kTtsChunk - n_fill);   // filler words beyond the open slice's room
                     const int64_t total_slices = n_sl + (extra > 0 ? (extra + kTtsChunk - 1) / kTtsChunk : 0);
                     if ((int64_t)(i - b0 + 1) + fillers > geo.max_slots || total_slices > kTtsMaxBlockSlices) close = true;
@@ -266,6 +297,7 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
     }
     S.words.resize((size_t)n_slices * kTtsChunk * 8);
     S.col_base.resize(cb_off[nt]); S.flags.resize(fl_off[nt]); S.chunk_info.resize(ci_off[nt]);
+    if (geo.gap_rows) S.flags_hi.resize(fl_off[nt]);
     double lines = 0; int64_t gathers = 0;
 #pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 1) reduction(+ : lines, gathers)
     for (long long tt = 0; tt < (long long)nt; ++tt) {
@@ -274,6 +306,7 @@ TtsStream build_tts(const Csr& m, int64_t target_tile_elems, TtsGeometry geo) {
         if (!o.words.empty()) std::memcpy(S.words.data() + w_off[t], o.words.data(), o.words.size());
         if (!o.col_base.empty()) std::memcpy(S.col_base.data() + cb_off[t], o.col_base.data(), o.col_base.size() * sizeof(int32_t));
         if (!o.flags.empty()) std::memcpy(S.flags.data() + fl_off[t], o.flags.data(), o.flags.size() * sizeof(uint16_t));
+        if (!o.flags_hi.empty()) std::memcpy(S.flags_hi.data() + fl_off[t], o.flags_hi.data(), o.flags_hi.size() * sizeof(uint16_t));
         if (!o.chunk_info.empty()) std::memcpy(S.chunk_info.data() + ci_off[t], o.chunk_info.data(), o.chunk_info.size() * sizeof(int32_t));
         lines += o.lines; gathers += o.gathers;
         o = TileOut{};

@@ -65,6 +65,12 @@ constexpr int kTtsPairedThreads = 512;
 struct TtsGeometry {
     int max_slots = kTtsMaxSlots, max_rows = kTtsMaxRows, tiles_wanted = 256;
     bool zero_fill = false;      // rows absent from a block own a slot but no stream word (the kernel keeps the staging zero-filled)
+    // GAP-CODED row ends (round 4): rows absent from a block own NOTHING -- no word, no slot.  A row end carries a 2-bit code, the
+    // distance (1..3) from the previous slot-owning row of the block to this one (a second plane of flag bits, `flags_hi`; a
+    // zero-valued filler slot breaks a run of more than two absent rows), and the kernel takes a row end's accumulator from the
+    // running sum of the codes instead of the running count of row ends.  What the tall geometry needed to pay off: its gathers
+    // touch 13 lines instead of 23, but with one slot per row and block its row-order pass had 46 % more slots to reduce.
+    bool gap_rows = false;
     int threads = kTtsThreads;   // workgroup size
 };
 
@@ -90,9 +96,11 @@ struct TtsStream {
     std::vector<TtsBlock> blocks;
     std::vector<uint8_t, DefaultInitAllocator<uint8_t>> words;   // per slice: 1024 x fp32 value, then 1024 x u32 meta (col_off << 16 | slot)
     std::vector<int32_t> col_base;       // per slice: column the 16-bit offsets are relative to
-    std::vector<uint16_t> flags;         // per chunk: 64 x u16, bit 4j+k of lane l = row end at slot 256j + 4l + k
+    std::vector<uint16_t> flags;         // per chunk: 64 x u16, bit 4j+k of lane l = row end at slot 256j + 4l + k (gap_rows: bit 0 of the code)
+    std::vector<uint16_t> flags_hi;      // gap_rows only: bit 1 of the row ends' codes, same layout (code = distance to the previous slot-owning row)
     std::vector<int32_t> chunk_info;     // per chunk: {rows ending before the chunk (tile-local), chain_len: the first row
-                                         //   ending in the chunk began this many chunks earlier}
+                                         //   ending in the chunk began this many chunks earlier}; gap_rows: {the last slot-owning row
+                                         //   BEFORE the chunk (-1: none), chain_len | code of the chunk's first row end << 16}
     std::vector<int32_t> fix;            // per row cut into pieces: {row, first carry, number of carries, 0} (the slice stream's FixEntry)
     int32_t n_carry = 0;
     int64_t n_fillers = 0, n_pad_words = 0;
@@ -101,7 +109,7 @@ struct TtsStream {
     TtsGeometry geometry;                // what it was packed for (padding words of phase A write to slot geometry.max_slots)
     int64_t total_slots = 0, max_tile_slots = 0;   // a tile is one workgroup's work: a tile far above the mean (one very long row) is the critical path
     int64_t bytes() const {
-        return (int64_t)words.size() + (int64_t)col_base.size() * 4 + (int64_t)flags.size() * 2 + (int64_t)chunk_info.size() * 4 +
+        return (int64_t)words.size() + (int64_t)col_base.size() * 4 + (int64_t)(flags.size() + flags_hi.size()) * 2 + (int64_t)chunk_info.size() * 4 +
                (int64_t)tiles.size() * 16 + (int64_t)blocks.size() * 32 + (int64_t)fix.size() * 4 + (int64_t)n_carry * 4;
     }
 };
@@ -120,6 +128,12 @@ inline TtsGeometry tts_tall_geometry(int n_cus, int parts) {
     return g;
 }
 constexpr int kTtsTallParts = 2;
+// The tall geometry with gap-coded row ends: the same tiles, no slot for an absent row, no zero-filled staging.
+inline TtsGeometry tts_tallgap_geometry(int n_cus, int parts) {
+    TtsGeometry g = tts_tall_geometry(n_cus, parts);
+    g.zero_fill = false; g.gap_rows = true;
+    return g;
+}
 inline TtsGeometry tts_paired_geometry(int n_cus) {
     TtsGeometry g;
     g.max_slots = kTtsPairedSlots; g.max_rows = kTtsMaxRows; g.tiles_wanted = n_cus; g.zero_fill = true; g.threads = kTtsPairedThreads;

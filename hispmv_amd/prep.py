@@ -38,8 +38,8 @@ def _collect_tts(p, target, geometry: int = 0):
     """geometry: 0 standard (8 K-row tiles), 1 small, "tall" = the list of the tall geometry's column parts (codes 2 + q)."""
     if isinstance(target, tuple):
         target, geometry = target
-    if geometry in ("tall", "paired"):
-        return [_collect_tts(p, target, (2 if geometry == "tall" else 4) + q) for q in range(2)]
+    if geometry in ("tall", "paired", "tallgap"):
+        return [_collect_tts(p, target, {"tall": 2, "paired": 4, "tallgap": 8}[geometry] + q) for q in range(2)]
     geometry = 6 if geometry == "zerofill" else int(geometry)
     cnt = (C.c_int64 * 8)()
     lpg = C.c_double()
@@ -56,7 +56,8 @@ def _collect_tts(p, target, geometry: int = 0):
         return a.reshape(shape) if shape else a
     pc = (C.c_int64 * 2)()
     lib.hispmv_prep_tts_pieces(p, pc)
-    return dict(zero_fill=geometry >= 2, n_tiles=tiles, n_blocks=blocks, n_slices=slices, n_chunks=chunks, fillers=fillers, pad_words=pads, max_rows=max_rows,
+    gap = geometry >= 8
+    return dict(zero_fill=2 <= geometry < 8, flags_hi=arr(7, chunks * 64, np.uint16, (-1, 64)) if gap else None, n_tiles=tiles, n_blocks=blocks, n_slices=slices, n_chunks=chunks, fillers=fillers, pad_words=pads, max_rows=max_rows,
                 max_slots=max_slots, lines_per_gather=float(lpg.value), n_carry=int(pc[1]), fix=arr(6, int(pc[0]) * 4, np.int32, (-1, 4)),
                 words=arr(0, slices * 2048, np.uint32, (-1, 2, 1024)), col_base=arr(1, slices, np.int32), flags=arr(2, chunks * 64, np.uint16, (-1, 64)),
                 chunk_info=arr(3, chunks * 2, np.int32, (-1, 2)), tiles=arr(4, tiles * 4, np.int32, (-1, 4)), blocks=arr(5, blocks * 8, np.int32, (-1, 8)))

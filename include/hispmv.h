@@ -254,7 +254,10 @@ int64_t hispmv_free_failures(void);
  * column part q (0 or 1) of the TALL geometry as the loader builds it for 256 CUs: the matrix cut at the column that halves
  * its elements, each half packed into tiles of <= 16384 rows and blocks of <= 23 K slots in which rows absent from a block
  * own a slot but no word (hispmv_matrix_info.group_slices = 23, col_tiles = 2: part 0 gives alpha*A_0*x + beta*bias, part 1
- * the partial vector alpha*A_1*x that the merge launch adds). */
+ * the partial vector alpha*A_1*x that the merge launch adds), 8 + q = column part q of the same geometry with GAP-CODED row
+ * ends (HISPMV_TTS_GEOMETRY=tallgap): absent rows own no slot, a row end's 2-bit code = bit of array 2 | bit of array 7 << 1
+ * (1 end, next row present; 2 end, one absent row follows; 3 end, two follow), chunk_info = {last slot-owning row before
+ * the chunk, chain_len | first code << 16}; array 7 = flags_hi (64 x u16 per chunk; null for the other geometries). */
 int hispmv_prep_build_tts(hispmv_prep* p, int64_t target_tile_elems, int small_geometry, int64_t counts[8], double* lines_per_gather);
 const void* hispmv_prep_tts_array(const hispmv_prep* p, int which);
 /* Rows longer than two tiles are cut into pieces, each a tile of its own; all but a row's last piece are carry tiles

@@ -72,7 +72,7 @@ def _load():
     lib.refpack_emulate.argtypes = [_p, _p, _p, C.c_float, C.c_float, _p]
     lib.emu_spmv.argtypes = [_p, _p, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int32, C.c_int]
     lib.emu_gemv.argtypes = [_p, C.c_int32, C.c_int32, _p, _p, C.c_float, C.c_float, _p]
-    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int]
+    lib.emu_tts.argtypes = [_p, _p, _p, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_int64, _p, _p, C.c_float, C.c_float, _p, C.c_int, _p]
     return lib
 
 
@@ -315,8 +315,10 @@ def emu_tts(tts, x, bias, alpha, beta, rows):
     xx, bb = _c(x, np.float32), _c(bias, np.float32)
     y = np.zeros(rows, dtype=np.float32)
     fx = _c(tts.get("fix", np.zeros((0, 4), np.int32)), np.int32)
+    fh = tts.get("flags_hi")
+    fh = _c(fh, np.uint16) if (fh is not None and np.size(fh)) else None        # gap-coded row ends (TtsGeometry::gap_rows)
     lib.emu_tts(_ptr(w), _ptr(cb), _ptr(fl), _ptr(ci), _ptr(ti), _ptr(bl), tts["n_tiles"], _ptr(fx), fx.shape[0], int(tts.get("n_carry", 0)),
-                _ptr(xx), _ptr(bb), alpha, beta, _ptr(y), int(bool(tts.get("zero_fill", False))))
+                _ptr(xx), _ptr(bb), alpha, beta, _ptr(y), int(bool(tts.get("zero_fill", False))), _ptr(fh) if fh is not None else None)
     return y
 
 

@@ -42,7 +42,7 @@ def make(case, rng):
 
 
 CASES = [(c, "standard") for c in ("uniform_short_rows", "empty_and_heavy_rows", "wide_columns_few_rows", "banded_jitter", "duplicates", "short_wide_layer")] + \
-        [(c, g) for g in ("tall", "paired", "zerofill") for c in ("uniform_short_rows", "empty_and_heavy_rows", "duplicates")]
+        [(c, g) for g in ("tall", "paired", "zerofill", "tallgap") for c in ("uniform_short_rows", "empty_and_heavy_rows", "duplicates")]
 
 
 @pytest.mark.parametrize("case,geometry", CASES)
@@ -62,11 +62,11 @@ def test_tile_stream_matches_its_model_and_the_fp64_truth(case, geometry, monkey
     idx = h.create_sparse_handle(r, c, v, rows, cols)
     h.load_matrices()
     info = h.matrix_info(idx)
-    assert info["format"] == 1 and info["group_slices"] == {"standard": 28, "tall": 23, "paired": 11, "zerofill": 28}[geometry]
+    assert info["format"] == 1 and info["group_slices"] == {"standard": 28, "tall": 23, "paired": 11, "zerofill": 28, "tallgap": 23}[geometry]
     assert info["col_tiles"] == (1 if geometry in ("standard", "zerofill") else 2)
     if geometry in ("standard", "zerofill"):
         assert info["n_split_rows"] == {"empty_and_heavy_rows": 2, "short_wide_layer": 1}.get(case, 0)      # rows cut into pieces (carry tiles + fix-up)
-    P = prep_from_coo(r, c, v, rows, cols, tts=(0, "zerofill" if geometry == "zerofill" else {13: 1, 28: 0, 23: "tall", 11: "paired"}[info["group_slices"]]))     # the geometry the loader chose
+    P = prep_from_coo(r, c, v, rows, cols, tts=(0, geometry if geometry in ("zerofill", "tallgap") else {13: 1, 28: 0, 23: "tall", 11: "paired"}[info["group_slices"]]))     # the geometry the loader chose
     rp = P.row_ptr.astype(np.int32)
     h.select_matrix(idx)
     for alpha, beta in ((ALPHA, BETA), (ALPHA_HOST, BETA_HOST), (1.0, 0.0), (-1.5, 0.5)):

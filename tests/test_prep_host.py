@@ -339,6 +339,41 @@ def test_transposed_tile_stream_packer_and_its_model(shape):
     assert bwd_err(y, y64, mag) < TOL
 
 
+@pytest.mark.parametrize("shape", [(60000, 80000, 300000), (30000, 30000, 40000), (20000, 500, 0)])
+def test_tall_tile_geometries_zero_filled_and_gap_coded(shape):
+    """The tall geometry's two column parts (16 K-row tiles): with zero-filled staging a row absent from a block owns a slot but no
+    word; with gap-coded row ends (tallgap) it owns nothing, and a row end says how many absent rows follow it (0, 1 or 2; a
+    filler breaks longer runs).  Both go through the CPU model of the kernel and must give the fp64 product; the gap code leaves
+    at most one filler per three absent rows where zero fill pays one slot for each."""
+    import oracle
+    rows, cols, nnz = shape
+    rng = np.random.default_rng(rows * 3 + nnz)
+    r = rng.integers(0, rows, nnz); c = rng.integers(0, cols, nnz)
+    if nnz:
+        r[rng.random(nnz) < 0.3] //= 7                     # a dense head and a sparse tail: long runs of absent rows
+    v = rng.random(nnz, dtype=np.float32) - np.float32(0.5)
+    x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
+    b = rng.random(rows, dtype=np.float32)
+    Pz = prep_from_coo(r, c, v, rows, cols, tts=(0, "tall"))
+    Pg = prep_from_coo(r, c, v, rows, cols, tts=(0, "tallgap"))
+    y64, mag = oracle.spmv_f64(Pz.row_ptr.astype(np.int32), Pz.col_idx, Pz.values, x, b, ALPHA, BETA)
+    for P in (Pz, Pg):
+        assert len(P.tts) == 2
+        assert bwd_err(oracle.emu_tts(P.tts, x, b, ALPHA, BETA, rows), y64, mag) < TOL
+    for q in range(2):
+        Tz, Tg = Pz.tts[q], Pg.tts[q]
+        assert Tz["flags_hi"] is None and Tg["flags_hi"].shape == Tg["flags"].shape
+        real = Tg["blocks"][:, 4].sum() - Tg["fillers"]
+        assert real == Tz["blocks"][:, 4].sum() - Tz["fillers"]         # the same elements, whatever the fillers
+        code = (Tg["flags"].astype(np.int64).reshape(-1)[:, None] >> np.arange(16) & 1) + 2 * (Tg["flags_hi"].astype(np.int64).reshape(-1)[:, None] >> np.arange(16) & 1)
+        ends, gaps = (code > 0).sum(), np.maximum(code - 1, 0).sum()
+        # every row of a tile is accounted for in every block: by a row end or by the gap behind one
+        want = sum(int(t[1]) * int(t[3]) for t in Tg["tiles"] if t[0] >= 0)
+        lead = want - ends - gaps                                       # absent rows before a block's first slot-owning row
+        assert 0 <= lead <= want
+        assert Tg["fillers"] <= Tz["fillers"] // 3 + len(Tg["blocks"]) + 1
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_flavours_agree_where_their_semantics_coincide(name):
     """bench.py feeds real .mtx files through flavour 1 (the cpu/ reader, pinned bit-exact by the reference itself); flavour 0
