@@ -18,6 +18,7 @@ FormatOptions FormatOptions::from_env() {
     if (const char* e = std::getenv("HISPMV_COL_TILE_BYTES")) o.col_tile_bytes = std::atoll(e);
     if (const char* e = std::getenv("HISPMV_TTS_MIN_NNZ")) o.tts_min_nnz = std::atoll(e);
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
+    if (const char* e = std::getenv("HISPMV_TTS_MAX_LINES")) o.tts_max_lines = std::atof(e);
     return o;
 }
 
@@ -325,7 +326,7 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
         // the tiles longest first, so this only rejects what is left: tiles capped by their row count next to full ones)
         const bool balanced = ts.max_tile_slots <= 2 * (ts.total_slots / std::max<int64_t>(1, (int64_t)ts.tiles.size())) + 4096;
         const bool fewer_requests = ts.lines_per_gather / 64.0 + 0.1 < slice_requests;     // (+0.1: the two passes and barriers of a block)
-        if (opt.format_mode == 1 || (ts.lines_per_gather <= 32.0 && balanced && fewer_requests)) {
+        if (opt.format_mode == 1 || (ts.lines_per_gather <= opt.tts_max_lines && balanced && fewer_requests)) {
             // The TALL geometry (hispmv_tts.h): when a gather of the 8 K-row tiles still touches many lines of x and x is
             // larger than an XCD's L2, the matrix becomes two column parts of 16 K-row tiles -- the same number of tiles
             // and elements per tile over half the column range (soc-Pokec: 23 -> 13 lines per gather), and in a batch

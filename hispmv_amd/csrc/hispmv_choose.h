@@ -33,6 +33,9 @@ struct FormatOptions {
     int64_t col_tile_bytes = 4 << 20;   // HISPMV_COL_TILE_BYTES: x bytes per L2-sized column tile (0 = no tiling)
     int64_t tts_min_nnz = 1 << 20;      // HISPMV_TTS_MIN_NNZ
     bool tts_small = false;             // HISPMV_TTS_SMALL (experiment)
+    double tts_max_lines = 48.0;        // HISPMV_TTS_MAX_LINES: a tile stream is taken when a gather of 64 elements touches at most this many lines of x
+                                        //   (32 until round 4: ASIC_680k, 34 lines, costs the step of the set 4 us less as 84 tiles than as 645 L2-gather
+                                        //   workgroups although it is no faster alone -- the step is the sum of its kernels' CU-time; r4_small_class.sh)
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
     static FormatOptions from_env();
 };

@@ -33,7 +33,7 @@ def test_pinned_choices_for_every_benchmarked_matrix():
     assert seen == set(GOLD), sorted(set(GOLD) ^ seen)
     # what the pins say, in words (the plans that carry the headline number)
     s = {k.split(":", 1)[1]: v for k, v in GOLD.items() if k.startswith("structured:")}
-    assert [n for n, v in s.items() if v["format"] == 1] == ["soc-Pokec", "nxp1", "analytics", "boyd2", "language"]
+    assert [n for n, v in s.items() if v["format"] == 1] == ["soc-Pokec", "ASIC_680k", "nxp1", "analytics", "boyd2", "language"]
     assert s["mouse_gene"]["tile_kind"] == 1 and s["mouse_gene"]["parts"] == 2 and s["mouse_gene"]["lds_floats"] > 0      # two LDS-window column tiles
     assert GOLD["uniform:PFlow_742"]["tile_kind"] == 2 and GOLD["uniform:Si41Ge41H72"]["tile_kind"] == 2                  # band tiles
     assert all(v["threads"] == 256 for n, v in s.items() if v["n_elems"] < (3 << 20) and v["format"] == 0)
