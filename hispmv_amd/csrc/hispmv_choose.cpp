@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -19,6 +20,7 @@ FormatOptions FormatOptions::from_env() {
     if (const char* e = std::getenv("HISPMV_TTS_MIN_NNZ")) o.tts_min_nnz = std::atoll(e);
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
     if (const char* e = std::getenv("HISPMV_TTS_MAX_LINES")) o.tts_max_lines = std::atof(e);
+    if (const char* e = std::getenv("HISPMV_TTS_TALL_SHAPE")) std::sscanf(e, "%d,%d,%d,%d,%d", &o.tall_rows, &o.tall_slots, &o.tall_tiles, &o.tall_zero_fill, &o.tall_parts);
     return o;
 }
 
@@ -339,12 +341,18 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
             const bool want_tall = opt.tts_geometry == 1 || paired || tallgap ||
                                    (opt.tts_geometry == 2 && ts.lines_per_gather > 16.0 && (int64_t)used * 4 > (4 << 20) && csr.rows >= 64 * kTtsTallRows);
             if (want_tall) {
-                const std::vector<int32_t> cuts = tts_column_cuts(csr, kTtsTallParts);
+                const int n_parts = opt.tall_parts > 0 ? opt.tall_parts : kTtsTallParts;
+                const std::vector<int32_t> cuts = tts_column_cuts(csr, n_parts);
                 double lines = 0; int64_t slices = 0;
                 bool ok = true;
-                for (int q = 0; q < kTtsTallParts && ok; ++q) {
-                    Csr part = csr_column_range(csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == kTtsTallParts ? csr.cols : cuts[(size_t)q]);
-                    tall.push_back(build_tts(part, 0, tallgap ? tts_tallgap_geometry(n_cus, kTtsTallParts) : paired ? tts_paired_geometry(n_cus) : tts_tall_geometry(n_cus, kTtsTallParts)));
+                for (int q = 0; q < n_parts && ok; ++q) {
+                    Csr part = csr_column_range(csr, q == 0 ? 0 : cuts[(size_t)q - 1], q + 1 == n_parts ? csr.cols : cuts[(size_t)q]);
+                    TtsGeometry geo = tallgap ? tts_tallgap_geometry(n_cus, n_parts) : paired ? tts_paired_geometry(n_cus) : tts_tall_geometry(n_cus, n_parts);
+                    if (opt.tall_rows > 0) geo.max_rows = opt.tall_rows;
+                    if (opt.tall_slots > 0) geo.max_slots = opt.tall_slots;
+                    if (opt.tall_tiles > 0) geo.tiles_wanted = opt.tall_tiles;
+                    if (opt.tall_zero_fill >= 0) geo.zero_fill = opt.tall_zero_fill != 0;
+                    tall.push_back(build_tts(part, 0, geo));
                     const TtsStream& t = tall.back();
                     lines += t.lines_per_gather * (double)t.col_base.size(); slices += (int64_t)t.col_base.size();
                     ok = t.max_tile_slots <= 2 * (t.total_slots / std::max<int64_t>(1, (int64_t)t.tiles.size())) + 4096;
@@ -365,7 +373,7 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
                 }
                 out.tts_lines_per_gather = lines / (double)std::max<int64_t>(slices, 1);
                 out.tile_kind = 1;
-                out.col_tile_width = tts_column_cuts(csr, kTtsTallParts)[0];
+                out.col_tile_width = tts_column_cuts(csr, (int)out.parts.size())[0];
             } else {
                 HostPart& p = out.parts[0];
                 p.is_tts = true;

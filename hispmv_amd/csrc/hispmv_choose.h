@@ -36,6 +36,7 @@ struct FormatOptions {
     double tts_max_lines = 48.0;        // HISPMV_TTS_MAX_LINES: a tile stream is taken when a gather of 64 elements touches at most this many lines of x
                                         //   (32 until round 4: ASIC_680k, 34 lines, costs the step of the set 4 us less as 84 tiles than as 645 L2-gather
                                         //   workgroups although it is no faster alone -- the step is the sum of its kernels' CU-time; r4_small_class.sh)
+    int tall_rows = 0, tall_slots = 0, tall_tiles = 0, tall_zero_fill = -1, tall_parts = 0;   // HISPMV_TTS_TALL_SHAPE=rows,slots,tiles per part,zero fill[,parts] (experiments; 0 / -1 = the geometry's own)
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
     static FormatOptions from_env();
 };

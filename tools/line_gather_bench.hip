@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256) void gather_lane(const uint32_t* __restrict__ 
     if (acc == 123.456f) out[wave] = acc;
 }
 
+// the same gathers with the table cut in two halves: workgroups of XCDs 0-3 (blockIdx mod 8 < 4) read the lower half, the others the
+// upper half -- what pinning the column parts of a tile stream to XCD subsets is meant to buy (an XCD's L2 holds half of x)
+__global__ __launch_bounds__(256) void gather_lane_halves(const uint32_t* __restrict__ cols, const float* __restrict__ x,
+                                                          float* __restrict__ out, long long n_groups, uint32_t half, int pinned) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long g0 = wave * kGroupsPerWave;
+    if (g0 >= n_groups) return;
+    const uint32_t off = (pinned ? (blockIdx.x & 4) != 0 : (blockIdx.x & 8) != 0) ? half : 0u;
+    uint32_t c[kGroupsPerWave];
+#pragma unroll
+    for (int g = 0; g < kGroupsPerWave; ++g) c[g] = cols[(g0 + g) * 64 + lane] % half + off;
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroupsPerWave; ++g) acc += x[c[g]];
+    if (acc == 123.456f) out[wave] = acc;
+}
+
 template <int NI, bool LDS>
 __global__ __launch_bounds__(256) void gather_line(const uint32_t* __restrict__ lines, const uint16_t* __restrict__ loc,
                                                    const float* __restrict__ x, float* __restrict__ out, long long n_groups) {
@@ -139,6 +157,8 @@ int main(int argc, char** argv) {
                sum_lines / n_groups, sum_lines64 / n_groups, max_lines, NI);
         dim3 grid((unsigned)((n_groups / kGroupsPerWave + 3) / 4)), blk(256);
         run("lane (dword gather)", [&] { hipLaunchKernelGGL(gather_lane, grid, blk, 0, 0, d_cols, d_x, d_out, n_groups); });
+        run("lane, halves by XCD", [&] { hipLaunchKernelGGL(gather_lane_halves, grid, blk, 0, 0, d_cols, d_x, d_out, n_groups, (uint32_t)(table_floats / 2), 1); });
+        run("lane, halves not by XCD", [&] { hipLaunchKernelGGL(gather_lane_halves, grid, blk, 0, 0, d_cols, d_x, d_out, n_groups, (uint32_t)(table_floats / 2), 0); });
 #define LINE(N) \
         if (NI == N) { \
             run("line loads + LDS", [&] { hipLaunchKernelGGL((gather_line<N, true>), grid, blk, 0, 0, d_lines, d_loc, d_x, d_out, n_groups); }); \
