@@ -830,6 +830,23 @@ def main():
             lin.append({"name": m["name"], "vectors": 8, "kernel_us": round(k * 1e6, 2), "call_us_with_pcie": round(w8 * 1e6, 1),
                         "gflops_kernel": round(8 * flops_of(m) / k / 1e9, 1),
                         "matrix_passes_per_s_x_bytes_GBs": round(alg_bytes(m) * 8 / k / 1e9, 1)})
+        # one vector per call from host buffers (FpgaHandle.run_kernel through linear's alpha = beta = 1): what apps/model_test.py pays per
+        # layer with --batch_size 1 -- the x / bias copy in, the launches, y written straight into pinned memory (no copy back)
+        one = []
+        for m in mats:
+            xs = rng.random(m["cols"], dtype=np.float32)
+            bias = rng.random(m["rows"], dtype=np.float32)
+            for _ in range(3):
+                fpga.linear(m["idx"], xs, bias)
+            ks, ws = [], []
+            for _ in range(15):
+                t1 = time.perf_counter()
+                fpga.linear(m["idx"], xs, bias)
+                ws.append(time.perf_counter() - t1)
+                ks.append(fpga.last_kernel_ms() * 1e-3)
+            one.append({"name": m["name"], "kernel_us": round(float(np.median(ks)) * 1e6, 2), "call_us_with_pcie": round(float(np.median(ws)) * 1e6, 1)})
+        extras["host_vector_call"] = {"layers": one, "note": "one vector per FpgaHandle.linear call from host buffers, median of 15; y lands in pinned "
+                                      "host memory without a copy back (HISPMV_HOST_Y=copy: through a device buffer, as until round 4)"}
         extras["linear_batch8"] = {"layers": lin, "note": "8 vectors per FpgaHandle.linear call; kernel_us is the device time of the launches, "
                                    "call_us_with_pcie the whole call from host buffers; the last column counts the matrix bytes once per "
                                    "vector, i.e. the rate a one-vector-per-pass kernel would need"}

@@ -635,19 +635,32 @@ static int run_host_vectors(hispmv_ctx* c, Matrix& m, const float* x, int64_t nu
             const int64_t want = std::max<int64_t>(nx + nb + ny, 1 << 16);
             HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, (size_t)want * sizeof(float), hipHostMallocDefault));
             c->cap_stage = want;
+            c->d_stage = nullptr;
+            // (HISPMV_HOST_Y=copy: y through a device buffer and a copy back, as until round 4)
+            const bool direct_y = !(std::getenv("HISPMV_HOST_Y") && !std::strcmp(std::getenv("HISPMV_HOST_Y"), "copy"));
+            if (direct_y && hipHostGetDevicePointer((void**)&c->d_stage, c->h_stage, 0) != hipSuccess) { (void)hipGetLastError(); c->d_stage = nullptr; }
         }
         std::memcpy(c->h_stage, x, bx);
         if (beta != 0.0f) std::memcpy(c->h_stage + nx, bias, bb);
-        HIP_TRY(c, hipMemcpyAsync(d_x, c->h_stage, beta != 0.0f ? (size_t)nx * sizeof(float) + bb : bx, hipMemcpyHostToDevice, c->stream));
+        // (x and bias cross PCIe through a copy KERNEL that reads the pinned block: the DMA path costs ~10 us per call; HISPMV_HOST_Y=copy: as before)
+        if (c->d_stage && (nx + nb) * (int64_t)sizeof(float) <= (1 << 20)) {
+            const hipError_t e = launch_fetch_vectors(c->d_stage, d_x, beta != 0.0f ? nx + nb : (int64_t)m.cols * num_vecs, c->stream);
+            if (e != hipSuccess) return hip_fail(c, e, "launch_fetch_vectors");
+        } else
+            HIP_TRY(c, hipMemcpyAsync(d_x, c->h_stage, beta != 0.0f ? (size_t)nx * sizeof(float) + bb : bx, hipMemcpyHostToDevice, c->stream));
     } else {
         HIP_TRY(c, hipMemcpyAsync(d_x, x, bx, hipMemcpyHostToDevice, c->stream));
         if (beta != 0.0f) HIP_TRY(c, hipMemcpyAsync(d_bias, bias, bb, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if ((rc = launch_matrix_vectors(c, m, num_vecs, d_x, d_bias, c->d_y, alpha, beta, c->stream, is_linear)) != HISPMV_OK) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    // Small vectors: the kernels write y STRAIGHT into the pinned staging block (its device address; coherent host memory), so the
+    // call has no copy back -- one DMA round trip (~10 us of a ~50 us call around a 10 - 20 us kernel) less.  The few read-modify-writes
+    // of y (rows cut by slice boundaries, the merge of column parts) cross PCIe; they run in the tail launch, one round trip deep.
     float* const h_y = staged ? c->h_stage + nx + nb : y;
-    HIP_TRY(c, hipMemcpyAsync(h_y, c->d_y, by, hipMemcpyDeviceToHost, c->stream));
+    float* const d_y = (staged && c->d_stage) ? c->d_stage + nx + nb : c->d_y;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if ((rc = launch_matrix_vectors(c, m, num_vecs, d_x, d_bias, d_y, alpha, beta, c->stream, is_linear)) != HISPMV_OK) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (d_y == c->d_y) HIP_TRY(c, hipMemcpyAsync(h_y, c->d_y, by, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (staged) std::memcpy(y, h_y, by);
     if (hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1) != hipSuccess) c->last_ms = -1.0f;

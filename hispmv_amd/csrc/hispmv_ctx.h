@@ -102,6 +102,7 @@ struct hispmv_ctx {
     // back through pinned memory too (pageable hipMemcpyAsync stages and synchronises per call: 3 copies + the error word
     // cost ~65 us around a 20 us kernel)
     float* h_stage = nullptr;
+    float* d_stage = nullptr;            // the device address of the same pinned block (run_kernel / linear write y straight into it)
     int64_t cap_stage = 0;
     // hispmv_spmv_device_batch: the launches of one call signature (handles, vectors, beta == 0 or not) with their device
     // tables, built on the first call and replayed afterwards

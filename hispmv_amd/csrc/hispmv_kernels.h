@@ -179,6 +179,8 @@ hipError_t launch_gemv_batched(const float* W, int32_t rows, int32_t cols, int64
 hipError_t graph_set_alpha(hipGraphExec_t exec, hipGraph_t graph, float alpha);
 
 // Multi-GPU boundary rows (hispmv.h: hispmv_boundary_pack / hispmv_boundary_apply).
+// n_floats floats (rounded up to whole float4s: both blocks are sized in multiples of 64 floats) from host-mapped memory to device memory
+hipError_t launch_fetch_vectors(const float* src, float* dst, int64_t n_floats, hipStream_t stream);
 hipError_t launch_boundary_pack(const float* const* last, const float* mask, float* send, int n, hipStream_t stream);
 hipError_t launch_boundary_apply(float* const* first, const float* recv, const float* weights, int n, int world,
                                  hipStream_t stream);

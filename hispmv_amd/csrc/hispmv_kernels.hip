@@ -1932,6 +1932,19 @@ __global__ void boundary_apply_kernel(float* const* __restrict__ first, const fl
     *first[i] += s;
 }
 
+// Host-vector path (hispmv_run_kernel / hispmv_linear with small vectors): x and bias from the pinned staging block (its device
+// address) into device memory -- a kernel instead of a DMA copy, whose engine costs ~10 us per call whatever the size.
+__global__ __launch_bounds__(256) void fetch_vectors_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < n4) dst[i] = src[i];
+}
+hipError_t launch_fetch_vectors(const float* src, float* dst, int64_t n_floats, hipStream_t stream) {
+    const int n4 = (int)((n_floats + 3) / 4);
+    if (n4 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fetch_vectors_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float4*)src, (float4*)dst, n4);
+    return hipGetLastError();
+}
+
 hipError_t launch_boundary_pack(const float* const* last, const float* mask, float* send, int n, hipStream_t stream) {
     (void)hipGetLastError();   // the status returned below must be this launch's, not a stale one of the thread (e.g. PyTorch's pointer queries)
     if (n <= 0) return hipSuccess;

@@ -2,6 +2,7 @@
 #include "hispmv_plan.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -149,6 +150,13 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
         if (c.threads == 1024 && G != 0 && n / G < 512) continue;   // big workgroups only when there are plenty
         if (G == 0) {
             G = (n + (int64_t)n_cus * c.per_cu - 1) / ((int64_t)n_cus * c.per_cu);
+            // experiment (r4_group_len.sh): HISPMV_PLAN_RESIDENT_DIV=d[,g] -- resident groups d times longer (a d-th of the CUs when the
+            // matrix runs alone) for plans whose groups would be shorter than g slices: fewer window-staging phases in a batch call
+            if (const char* e = std::getenv("HISPMV_PLAN_RESIDENT_DIV")) {
+                int d = 1, below = 1 << 30;
+                std::sscanf(e, "%d,%d", &d, &below);
+                if (d > 1 && G < below) G = (n + (int64_t)(n_cus / d) * c.per_cu - 1) / ((int64_t)(n_cus / d) * c.per_cu);
+            }
             static const int min_resident = std::getenv("HISPMV_PLAN_MIN_RESIDENT") ? std::atoi(std::getenv("HISPMV_PLAN_MIN_RESIDENT")) : 0;
             if (G < (min_resident > 0 ? min_resident : c.threads == 1024 ? 16 : 24)) continue;   // too little work to be worth a resident grid
         } else {

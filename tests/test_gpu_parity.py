@@ -705,6 +705,76 @@ def test_device_resident_entry_point_matches_host_path(fpga):
     assert 0 < ms < 50
 
 
+_LINEAR_BITS = {}
+
+
+def oracle_linear(case, v, W, x, b):
+    """fp64 y = A x + b and the magnitude sum of its terms, for a COO case or the dense W."""
+    r, c, nr, nc = case
+    if r is None:
+        return W.astype(np.float64) @ x.astype(np.float64) + b, np.abs(W).astype(np.float64) @ np.abs(x).astype(np.float64) + np.abs(b)
+    t = np.zeros(nr); m = np.zeros(nr)
+    p = v.astype(np.float64) * x.astype(np.float64)[c]
+    np.add.at(t, r, p); np.add.at(m, r, np.abs(p))
+    return t + b, m + np.abs(b)
+
+
+@pytest.mark.parametrize("mode", ["direct", "copy"])
+def test_host_vector_path_direct_and_copied_y(pyhispmv_mod, mode, monkeypatch):
+    """run_kernel / linear from host buffers: by default x and bias reach the device through a fetch kernel that reads the pinned
+    staging block and y is written straight into that block (no DMA copies: hispmv_abi.cpp run_host_vectors); HISPMV_HOST_Y=copy keeps
+    the copies.  Both give the bits of the device entry point -- for a slice stream with cut rows (the tail's read-modify-writes of y
+    cross PCIe), a matrix in two column parts (partial vector + merge), a dense handle, 5 vectors per linear call, beta = 0, and a
+    matrix whose vectors are too large for the staging block (> 8 MB: plain copies in both modes)."""
+    import torch
+    monkeypatch.setenv("HISPMV_HOST_Y", mode)
+    h = pyhispmv_mod.FpgaHandle(*HW)
+    rng = np.random.default_rng(5)
+    cases = []
+    rows, cols, nnz = 30000, 26000, 900000                      # long rows: many rows cut by slice boundaries
+    r = rng.integers(0, rows // 50, nnz).astype(np.int32) * 50; c = rng.integers(0, cols, nnz).astype(np.int32)
+    cases.append((r, c, rows, cols))
+    rows2 = 6000; cols2 = 60000                                # x of 240 KB on short rows: two LDS-window column tiles
+    r2 = np.repeat(np.arange(rows2, dtype=np.int32), 700); c2 = rng.integers(0, cols2, r2.size).astype(np.int32)
+    cases.append((r2, c2, rows2, cols2))
+    rows3 = cols3 = 1200000                                     # 4.8 MB vectors: x + bias + y exceed the staging threshold
+    r3 = rng.integers(0, rows3, 2000000).astype(np.int32); c3 = rng.integers(0, cols3, r3.size).astype(np.int32)
+    cases.append((r3, c3, rows3, cols3))
+    idxs, vals = [], []
+    for (rr, cc, nr, nc) in cases:
+        vals.append(rng.random(rr.size, dtype=np.float32) - np.float32(0.5))
+        idxs.append(h.create_sparse_handle(rr, cc, vals[-1], nr, nc))
+    vals.append(None)
+    W = rng.standard_normal((300, 700), dtype=np.float32)
+    idxs.append(h.create_dense_handle(W.flatten(), 300, 700))
+    cases.append((None, None, 300, 700))
+    h.load_matrices()
+    dev = torch.device("cuda", 0)
+    for idx, (_, _, nr, nc) in zip(idxs, cases):
+        x = rng.random(nc, dtype=np.float32) - np.float32(0.3)
+        b = rng.random(nr, dtype=np.float32)
+        dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+        h.select_matrix(idx)
+        for alpha, beta in ((ALPHA, BETA), (1.25, 0.0)):
+            dy = torch.full((nr,), float("nan"), dtype=torch.float32, device=dev)
+            h.spmv_device(idx, dx.data_ptr(), db.data_ptr(), dy.data_ptr(), alpha, beta, None)
+            h.synchronize()
+            for _ in range(2):
+                y = np.full(nr, np.nan, np.float32)
+                h.run_kernel(x, b, y, alpha, beta)
+                assert np.array_equal(y.view(np.uint32), dy.cpu().numpy().view(np.uint32)), (mode, idx, alpha, beta)
+        if nr * 5 * 4 < (4 << 20):
+            X = rng.random(5 * nc, dtype=np.float32)
+            out = h.linear(idx, X, b)
+            y64 = [oracle_linear(cases[idxs.index(idx)], vals[idxs.index(idx)], W, X[k * nc:(k + 1) * nc], b) for k in range(5)]
+            for k in range(5):
+                t, mag = y64[k]
+                assert bwd_err(out[k * nr:(k + 1) * nr], t, mag) < TOL
+            _LINEAR_BITS.setdefault(idx, out.copy())            # (the same seeds in both modes: the second one must reproduce the first)
+            assert np.array_equal(out.view(np.uint32), _LINEAR_BITS[idx].view(np.uint32)), (mode, idx)
+    h.close()
+
+
 def test_wide_band_is_cut_along_the_diagonal(fpga):
     """Band tiles (hispmv_matrix_info.tile_kind 2): a banded matrix whose band (+-24000 here) is wider than an LDS window is cut
     into ranges of the offset from the diagonal; every part then runs with its x window in LDS and 6-byte elements.  Bitwise
