@@ -86,6 +86,15 @@ def test_branches_and_switches():
     # the tall geometry of a tile stream: two column parts
     d = _choose_in_child({"HISPMV_BAND_TILES": "0", "HISPMV_TTS_GEOMETRY": "tall"}, wide)
     assert d["format"] == 1 and d["parts"] == 2 and d["tile_kind"] == 1 and d["tile_width"] > 0
+    # ... and the experiment knob for other shapes of the column parts (rows, slots, tiles per part, zero fill, parts)
+    d = _choose_in_child({"HISPMV_BAND_TILES": "0", "HISPMV_TTS_GEOMETRY": "tall", "HISPMV_TTS_TALL_SHAPE": "8192,28672,256,0,4"}, wide)
+    assert d["format"] == 1 and d["parts"] == 4 and d["group"] == 28
+    # a gather of 64 column-sorted elements that touches 32 - 48 lines of x: a tile stream since round 4 (HISPMV_TTS_MAX_LINES, default
+    # 48: ASIC_680k's case -- fewer, longer-lived workgroups cost the step of the benchmark set less than 645 L2-gather groups)
+    sparse = "_band(800000, 2, 400000)"
+    d = _choose_in_child({}, sparse)
+    assert d["format"] == 1 and 32000 < d["lines_per_gather_x1000"] <= 48000
+    assert _choose_in_child({"HISPMV_TTS_MAX_LINES": "32"}, sparse)["format"] == 0
     # stray couplings: 3 % of a narrow band's entries at random columns -> split into the windowed part and the strays (tile_kind 3);
     # 12 % strays of the same band still split (<= 15 %), and the switch turns it off
     strays = "(lambda t: (t[0], np.sort(np.where(np.random.default_rng(5).random(t[1].size) < %s, np.random.default_rng(6).integers(0, 300000, t[1].size), t[1]).reshape(300000, 16), axis=1).reshape(-1).astype(np.int32), t[2]))(_band(300000, 16, 1500))"
