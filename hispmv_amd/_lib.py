@@ -86,6 +86,7 @@ SIGNATURES = {
     "hispmv_prep_groups": (_i32p, [_p]),
     "hispmv_prep_device_stream": (C.c_int, [_p, _i64p]),
     "hispmv_prep_device_array": (C.c_void_p, [_p, C.c_int]),
+    "hispmv_prep_device_stream_on_device": (C.c_int, [_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hispmv_prep_frags": (_i32p, [_p]),
     "hispmv_prep_csr_row_ptr": (_i64p, [_p]),
     "hispmv_prep_csr_col": (_i32p, [_p]),

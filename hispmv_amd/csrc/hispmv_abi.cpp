@@ -39,7 +39,7 @@ int check_device_error(hispmv_ctx* c) {
 namespace {
 
 int64_t sparse_device_bytes(const SliceStream& st, const DeviceStream& ds) {
-    return (int64_t)ds.bytes.size() + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
+    return ds.n_bytes + (int64_t)st.hdr.size() * 16 + (int64_t)st.fix.size() * 16 +
            (int64_t)st.n_slices * 12 + 8;
 }
 
@@ -92,7 +92,7 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             m->device_bytes += p.tts.bytes();
         } else {
             m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
-            m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16 + (int64_t)p.dstream.stray_cols.size() * 4;
+            m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16 + (p.dstream.any_stray ? p.st.n_slices * (int64_t)kStraySlots * 4 : 0);
             m->compact_slices += p.dstream.compact_slices;
         }
     }
@@ -440,6 +440,8 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         Matrix& m = *mp;
         if (m.loaded) continue;
         int rc;
+        // (scratch of the device layout -- the uploaded host words of the parts --, freed once the stream has drained, also on an error return)
+        struct Scratch { std::vector<void*> v; void push_back(void* p) { v.push_back(p); } ~Scratch() { for (void* p : v) (void)hipFree(p); } } layout_scratch;
         std::vector<std::vector<int32_t>> tts_fix_rows;       // tile streams: the rows cut into pieces, per part (fix list order)
         if (m.dense) {
             const float* d = nullptr;
@@ -502,7 +504,21 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 const int64_t ns = p.st.n_slices;
                 if ((rc = upload(c, m, p.dstream.groups.data(), p.dstream.groups.size(), &dg)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.plan.frags.data(), p.plan.frags.size(), &dfr)) != HISPMV_OK) return rc;
-                if ((rc = upload(c, m, p.dstream.bytes.data(), p.dstream.bytes.size(), &dw)) != HISPMV_OK) return rc;
+                // the slices in their device layout: packed on the host (HISPMV_LAYOUT=host) or laid out HERE from the uploaded host words
+                const bool lay_out = p.dstream.bytes.empty() && p.dstream.n_bytes > 0;
+                uint64_t* d_host_words = nullptr;
+                if (!lay_out) {
+                    if ((rc = upload(c, m, p.dstream.bytes.data(), p.dstream.bytes.size(), &dw)) != HISPMV_OK) return rc;
+                } else {
+                    if ((int64_t)p.st.words.size() != ns * kSliceElems) return fail(c, HISPMV_EINVAL, "internal: host words missing for the device layout");
+                    void* blk = nullptr;
+                    HIP_TRY(c, hipMalloc(&blk, (size_t)p.dstream.n_bytes));
+                    m.allocs.push_back(blk);
+                    dw = (const uint8_t*)blk;
+                    HIP_TRY(c, hipMalloc((void**)&d_host_words, p.st.words.size() * sizeof(uint64_t)));
+                    layout_scratch.push_back(d_host_words);
+                    HIP_TRY(c, hipMemcpyAsync(d_host_words, p.st.words.data(), p.st.words.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                }
                 // device header: {row_base, chain_len, rows ending in the slice, 1 if some of its elements lie outside
                 // the group's x window} (the column window of a slice is only needed by the planner)
                 std::vector<SliceHdr>& hh = p.st.hdr;
@@ -513,8 +529,18 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                     hh[sl].x_span = (!p.plan.slice_spills.empty() && p.plan.slice_spills[(size_t)sl]) ? 1 : 0;
                     max_rows = std::max(max_rows, nr);
                 }
-                if (p.dstream.stray_cols.empty()) {
+                uint32_t* d_stray_cols = nullptr;
+                if (!p.dstream.any_stray) {
                     if ((rc = upload(c, m, hh.data(), hh.size(), &dh)) != HISPMV_OK) return rc;
+                } else if (lay_out) {
+                    void* blk = nullptr;
+                    const size_t hb = hh.size() * sizeof(SliceHdr), sb = (size_t)ns * kStraySlots * sizeof(uint32_t);
+                    HIP_TRY(c, hipMalloc(&blk, hb + sb));
+                    m.allocs.push_back(blk);
+                    HIP_TRY(c, hipMemcpyAsync(blk, hh.data(), hb, hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(c, hipMemsetAsync((char*)blk + hb, 0xff, sb, c->stream));        // 0xffffffff = no stray
+                    dh = (const SliceHdr*)blk;
+                    d_stray_cols = (uint32_t*)((char*)blk + hb);
                 } else {
                     // stray slots: the columns of every slice's strays (64 x u32 per slice) live BEHIND the headers in one
                     // allocation -- the kernels reach them as hdr + n_slices, no further pointer to carry around
@@ -525,6 +551,11 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                     HIP_TRY(c, hipMemcpyAsync(blk, hh.data(), hb, hipMemcpyHostToDevice, c->stream));
                     HIP_TRY(c, hipMemcpyAsync((char*)blk + hb, p.dstream.stray_cols.data(), sb, hipMemcpyHostToDevice, c->stream));
                     dh = (const SliceHdr*)blk;
+                }
+                if (lay_out) {
+                    const int e = layout_on_device(d_host_words, ns, p.plan.group_slices, dg, p.plan.lds_floats, p.plan.block_threads / 64,
+                                                   (uint8_t*)dw, d_stray_cols, c->stream);
+                    if (e != 0) return hip_fail(c, (hipError_t)e, "layout_on_device");
                 }
                 if ((rc = upload(c, m, p.fix_short.data(), p.fix_short.size(), &fs)) != HISPMV_OK) return rc;
                 if ((rc = upload(c, m, p.fix_long.data(), p.fix_long.size(), &fl)) != HISPMV_OK) return rc;

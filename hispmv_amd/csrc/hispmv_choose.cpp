@@ -19,6 +19,8 @@ FormatOptions FormatOptions::from_env() {
     if (const char* e = std::getenv("HISPMV_COL_TILE_BYTES")) o.col_tile_bytes = std::atoll(e);
     if (const char* e = std::getenv("HISPMV_TTS_MIN_NNZ")) o.tts_min_nnz = std::atoll(e);
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
+    o.no_stream_skip = std::getenv("HISPMV_NO_STREAM_SKIP") != nullptr;
+    if (const char* e = std::getenv("HISPMV_LAYOUT")) o.device_layout = !std::strcmp(e, "device");
     if (const char* e = std::getenv("HISPMV_TTS_MAX_LINES")) o.tts_max_lines = std::atof(e);
     if (const char* e = std::getenv("HISPMV_TTS_TALL_SHAPE")) std::sscanf(e, "%d,%d,%d,%d,%d", &o.tall_rows, &o.tall_slots, &o.tall_tiles, &o.tall_zero_fill, &o.tall_parts);
     return o;
@@ -105,10 +107,33 @@ void plan_part(HostPart& p, int n_cus) {
 }
 void pack_part(HostPart& p, const FormatOptions& opt) {
     if (opt.decide_only) return;
-    p.dstream = pack_device_stream(p.st, p.plan);
-    p.st.words = WordVec();   // the device layout replaces the host words
+    p.dstream = pack_device_stream(p.st, p.plan, !opt.device_layout);
+    if (!opt.device_layout) p.st.words = WordVec();   // the device layout replaces the host words (else the loader uploads them and lays them out there)
 }
 void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p, n_cus); pack_part(p, opt); }
+
+// "No x window can pay", decided from 32 samples of the CSR instead of from the launch plan of a slice stream: in every sample --
+// 8192 consecutive entries, the elements of the SMALLEST group any plan has (8 slices) -- at least 90 % of the entries sit in a
+// 64-byte block of x of their own.  A window then holds one element per staged block whatever the group size (larger groups touch
+// more blocks, not fewer per element), which is what make_plan prices as "gather through L2" (cost >= 0.8).  Lets the loader skip
+// building a slice stream it would drop for a tile stream: 44 + 7 ms of 154 on soc-Pokec's shape.
+bool sampled_scattered(const Csr& csr) {
+    const int64_t nnz = csr.nnz();
+    constexpr int64_t kSample = 8 * kSliceElems;
+    constexpr int kSamples = 32;
+    if (nnz < kSamples * kSample) return false;
+    int bad = 0;
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(+ : bad)
+    for (int sidx = 0; sidx < kSamples; ++sidx) {
+        const int64_t k0 = (nnz - kSample) * sidx / (kSamples - 1);
+        std::vector<int32_t> b((size_t)kSample);
+        for (int64_t k = 0; k < kSample; ++k) b[(size_t)k] = csr.col[(size_t)(k0 + k)] / kFragBlock;
+        std::sort(b.begin(), b.end());
+        const int64_t distinct = std::unique(b.begin(), b.end()) - b.begin();
+        if (distinct * 10 < kSample * 9) ++bad;
+    }
+    return bad == 0;
+}
 
 }  // namespace
 
@@ -137,10 +162,29 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     auto lap = [&](const char* what) { if (lap_fn) lap_fn(what); };
     FormatChoice out;
     out.parts.emplace_back();
-    out.parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
-    lap("slice stream (host) / adopt");
-    plan_part(out.parts[0], n_cus);            // (its device layout: once the format is decided, below)
-    lap("launch plan");
+    // The whole-matrix slice stream and its launch plan -- unless the samples already say that no window pays and a tile stream is
+    // on the cards (auto mode, at least tts_min_nnz entries): then the plan is the planner's "gather through L2" default, and the
+    // stream is built only if the tile stream is turned down further below.
+    bool have_stream = true;
+    if (!prebuilt && opt.format_mode == 2 && !opt.no_stream_skip && csr.nnz() >= std::max<int64_t>(opt.tts_min_nnz, 1 << 20) && sampled_scattered(csr)) {
+        have_stream = false;
+        LaunchPlan& d = out.parts[0].plan;
+        d.block_threads = 256; d.group_slices = 8; d.lds_floats = 0; d.per_cu = 4;
+        lap("sampled: scattered (no slice stream)");
+    } else {
+        out.parts[0].st = prebuilt ? std::move(*prebuilt) : build_stream(csr);      // (the device preprocessor hands its stream over)
+        lap("slice stream (host) / adopt");
+        plan_part(out.parts[0], n_cus);            // (its device layout: once the format is decided, below)
+        lap("launch plan");
+    }
+    auto ensure_stream = [&]() {
+        if (have_stream) return;
+        out.parts[0] = HostPart();
+        out.parts[0].st = build_stream(csr);
+        plan_part(out.parts[0], n_cus);
+        have_stream = true;
+        lap("slice stream + plan (tile stream turned down)");
+    };
     // Column tiling when the whole-matrix plan has to gather x through L2:
     //  * x a little too large for one LDS window (<= 2 windows): two tiles, each with its x window in LDS;
     //  * x larger than an XCD's L2: L2-sized tiles.
@@ -187,12 +231,12 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     // Candidates: plans without a window, and plans whose window leaves more than 5 % of the gathers to L2 (a wide band
     // without column reuse between rows: the pessimistic stand-ins of PFlow_742 / Si41Ge41H72, 86 and 69 us with a 128 KiB
     // window of the most used blocks) -- there the two formats are compared by their L2 requests per element.
-    const int64_t all_elems = out.parts[0].st.n_slices * (int64_t)kSliceElems;
+    const int64_t all_elems = have_stream ? out.parts[0].st.n_slices * (int64_t)kSliceElems : nnz_all;
     const double slice_requests = whole.lds_floats == 0 ? 1.0
                                  : ((double)whole.global_elems + (double)whole.staged_floats / kFragBlock) / (double)std::max<int64_t>(all_elems, 1);
     // (x at most two windows wide is cut into two column tiles that each run from LDS: mouse_gene 56 us that way, 77 us as
     // a tile stream)
-    const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && opt.col_tile_bytes > 0 && out.parts[0].st.n_slices >= 4096;
+    const bool two_windows = used > 0 && used <= 2 * kMaxLdsFloats && opt.col_tile_bytes > 0 && (have_stream ? out.parts[0].st.n_slices : nnz_all / kSliceElems) >= 4096;
     const bool candidate = whole.lds_floats == 0 || (whole.global_elems * 20 > all_elems && !two_windows);
     // (x of at most 256 KiB stays in L1 / L2 whatever the order of the gathers: the slice stream's per-element gathers are cheap
     // there and a tile is a longer latency chain -- the 1024 x 8192 layer of apps/model_test.py: 10.0 us as a slice stream
@@ -385,6 +429,7 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
             return out;
         }
     }
+    ensure_stream();
     // (a window that leaves more than a tenth of the gathers to L2 counts as "does not fit" here)
     const bool spilling = whole.lds_floats > 0 && whole.global_elems * 10 > out.parts[0].st.n_slices * (int64_t)kSliceElems;
     if (used > 0 && (whole.lds_floats == 0 || spilling)) {

@@ -37,6 +37,10 @@ struct FormatOptions {
                                         //   (32 until round 4: ASIC_680k, 34 lines, costs the step of the set 4 us less as 84 tiles than as 645 L2-gather
                                         //   workgroups although it is no faster alone -- the step is the sum of its kernels' CU-time; r4_small_class.sh)
     int tall_rows = 0, tall_slots = 0, tall_tiles = 0, tall_zero_fill = -1, tall_parts = 0;   // HISPMV_TTS_TALL_SHAPE=rows,slots,tiles per part,zero fill[,parts] (experiments; 0 / -1 = the geometry's own)
+    bool no_stream_skip = false;  // HISPMV_NO_STREAM_SKIP: always build the whole-matrix slice stream before deciding (round 3's order)
+    bool device_layout = false;   // HISPMV_LAYOUT=device: the slice streams keep their 8-byte host words and the loader lays them out on the
+                                  //   device (layout_on_device, byte-identical).  Off by default: the upload of the larger words from pageable
+                                  //   memory costs more than the host packer saves (set of 20: prep + upload 1.38 s against 1.22 s)
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
     static FormatOptions from_env();
 };

@@ -307,7 +307,7 @@ double stray_slot_coverage(const SliceStream& st, const LaunchPlan& plan) {
     return all > 0 ? (double)covered / (double)all : 0.0;
 }
 
-DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan) {
+DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan, bool materialize) {
     DeviceStream d;
     const int64_t n = st.n_slices, G = plan.group_slices;
     const int64_t ng = std::max<int64_t>((n + G - 1) / G, 1);
@@ -329,11 +329,12 @@ DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan) {
         if (compact[(size_t)g] == 3) d.stray_slices += std::max<int64_t>(s1 - s0, 0);
     }
     if (off[(size_t)ng] / kSliceUnit > INT32_MAX) throw std::length_error("stream larger than 4 TiB");
+    d.n_bytes = off[(size_t)ng];
+    d.any_stray = any_stray;
+    if (any_stray) d.stray_floats = n_waves * kStraySlots;
+    if (!materialize) return d;
     d.bytes.resize((size_t)off[(size_t)ng]);
-    if (any_stray) {
-        d.stray_floats = n_waves * kStraySlots;
-        d.stray_cols.assign((size_t)n * kStraySlots, 0xffffffffu);
-    }
+    if (any_stray) d.stray_cols.assign((size_t)n * kStraySlots, 0xffffffffu);
 #pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 4)
     for (int64_t g = 0; g < ng; ++g) {
         const int64_t s0 = g * G, s1 = std::min(n, s0 + G);

@@ -68,8 +68,12 @@ struct DeviceStream {
     std::vector<uint32_t> stray_cols;    // n_slices x kStraySlots columns (0xffffffff = unused), empty when no group uses stray slots
     int stray_floats = 0;                // LDS floats of the stray areas (wavefronts x kStraySlots) behind the window, 0 = none
     int64_t compact_slices = 0, stray_slices = 0;
+    int64_t n_bytes = 0;                 // size of `bytes`, also when they are left to the device (materialize = false)
+    bool any_stray = false;              // some group uses stray slots (stray_cols has n_slices x kStraySlots entries once materialized)
 };
-DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan);
+// materialize = false: the group table, sizes and flags only -- the loader then runs layout_on_device (hispmv_prep_device.h) over the
+// uploaded host words, which writes the same bytes and stray columns.
+DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan, bool materialize = true);
 // Share of the plan's elements outside their windows that stray slots will serve (groups whose slices have <= kStraySlots each).
 double stray_slot_coverage(const SliceStream& st, const LaunchPlan& plan);
 

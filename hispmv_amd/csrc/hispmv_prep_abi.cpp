@@ -140,6 +140,30 @@ HISPMV_API int hispmv_prep_device_stream(hispmv_prep* p, int64_t counts[6]) {
         return HISPMV_OK;
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
 }
+// The same layout written by the DEVICE (layout_on_device, what hispmv_load_matrices runs with HISPMV_LAYOUT=device) from the planned host words:
+// call hispmv_prep_apply_plan and hispmv_prep_device_stream first; bytes_out takes counts[0] bytes, stray_cols_out n_slices x 64 u32
+// (may be null when counts[4] == 0).  For tests: device == host, byte for byte.
+HISPMV_API int hispmv_prep_device_stream_on_device(hispmv_prep* p, int device_id, uint8_t* bytes_out, uint32_t* stray_cols_out) {
+    if (!p || !bytes_out) return HISPMV_EINVAL;
+    if (p->dstream.groups.empty() || (int64_t)p->st.words.size() != p->st.n_slices * kSliceElems) { g_prep_err = "call hispmv_prep_apply_plan and hispmv_prep_device_stream first"; return HISPMV_ESTATE; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_prep_err = "no such HIP device"; return HISPMV_EDEVICE; }
+    const int64_t ns = p->st.n_slices;
+    const size_t wb = p->st.words.size() * sizeof(uint64_t), gb = p->dstream.groups.size() * sizeof(int32_t), sb = (size_t)ns * kStraySlots * sizeof(uint32_t);
+    void *dw = nullptr, *dg = nullptr, *db = nullptr, *ds = nullptr;
+    auto done = [&](int rc, const char* what) { if (rc != HISPMV_OK) g_prep_err = what; (void)hipFree(dw); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(ds); return rc; };
+    if (hipMalloc(&dw, std::max<size_t>(wb, 8)) != hipSuccess || hipMalloc(&dg, gb) != hipSuccess || hipMalloc(&db, std::max<int64_t>(p->dstream.n_bytes, 8)) != hipSuccess)
+        return done(HISPMV_EDEVICE, "hipMalloc failed");
+    const bool strays = p->dstream.any_stray && stray_cols_out;
+    if (strays && (hipMalloc(&ds, sb) != hipSuccess || hipMemset(ds, 0xff, sb) != hipSuccess)) return done(HISPMV_EDEVICE, "hipMalloc failed");
+    if (hipMemcpy(dw, p->st.words.data(), wb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dg, p->dstream.groups.data(), gb, hipMemcpyHostToDevice) != hipSuccess)
+        return done(HISPMV_EDEVICE, "hipMemcpy failed");
+    if (layout_on_device((const uint64_t*)dw, ns, p->plan.group_slices, (const int32_t*)dg, p->plan.lds_floats, p->plan.block_threads / 64, (uint8_t*)db, (uint32_t*)ds, nullptr) != 0)
+        return done(HISPMV_EDEVICE, "layout kernel launch failed");
+    if (hipDeviceSynchronize() != hipSuccess) return done(HISPMV_EDEVICE, "layout kernel failed");
+    if (hipMemcpy(bytes_out, db, (size_t)p->dstream.n_bytes, hipMemcpyDeviceToHost) != hipSuccess) return done(HISPMV_EDEVICE, "hipMemcpy failed");
+    if (strays && hipMemcpy(stray_cols_out, ds, sb, hipMemcpyDeviceToHost) != hipSuccess) return done(HISPMV_EDEVICE, "hipMemcpy failed");
+    return done(HISPMV_OK, "");
+}
 HISPMV_API const void* hispmv_prep_device_array(const hispmv_prep* p, int which) {
     if (!p) return nullptr;
     switch (which) {

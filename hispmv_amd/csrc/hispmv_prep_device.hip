@@ -218,4 +218,70 @@ bool prep_on_device(int32_t rows, int32_t cols, int64_t nnz, const int32_t* r, c
     return true;
 }
 
+// ---- device layout of a planned slice stream (pack_device_stream, hispmv_plan.cpp) ------------------------------------------
+// One 256-thread workgroup per slice, 4 consecutive elements per thread.
+__global__ __launch_bounds__(256) void layout_slices_kernel(const uint64_t* __restrict__ words, long long n_slices, int G, const int4* __restrict__ groups,
+                                                            int window_floats, int n_waves, uint8_t* __restrict__ bytes, uint32_t* __restrict__ stray_cols) {
+    __shared__ int wave_strays[4];
+    const long long sl = blockIdx.x;
+    const long long g = sl / G, s0 = g * G;
+    const long long s1 = s0 + G < n_slices ? s0 + G : n_slices;
+    const int n_here = (int)(s1 - s0);
+    const int4 gd = groups[g];                       // {frag_begin, frag_count, offset in kSliceUnit, 1 compact | 2 stray slots}
+    const bool compact = gd.w != 0;
+    uint8_t* const base = bytes + (size_t)(unsigned)gd.z * kSliceUnit + (size_t)(sl - s0) * (compact ? kCompactSliceBytes : kWideSliceBytes);
+    const int t = (int)threadIdx.x, i0 = 4 * t;
+    const uint64_t* w = words + sl * kSliceElems + i0;
+    uint64_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = w[k];
+    uint4 v;
+    v.x = (uint32_t)e[0]; v.y = (uint32_t)e[1]; v.z = (uint32_t)e[2]; v.w = (uint32_t)e[3];
+    ((uint4*)base)[t] = v;
+    uint32_t m[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = (uint32_t)(e[k] >> 32);
+    if (!compact) {
+        uint4 q; q.x = m[0]; q.y = m[1]; q.z = m[2]; q.w = m[3];
+        ((uint4*)(base + kSliceElems * 4))[t] = q;
+        return;
+    }
+    // strays of the slice in element order: count per thread, exclusive scan over the workgroup
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine += (m[k] & kGlobalColBit) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
+    if ((t & 63) == 63) wave_strays[t >> 6] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int q = 0; q < (t >> 6); ++q) before += wave_strays[q];
+    const int rot = n_here > 0 ? (int)(((unsigned long long)g * 29ull) % (unsigned long long)n_here) : 0;      // the kernel's walk (slices_group)
+    const int pos = (int)(((sl - s0) - rot + n_here) % n_here);
+    const uint32_t area = (uint32_t)window_floats + (uint32_t)(pos % n_waves) * kStraySlots;
+    uint16_t out[4];
+    int k_stray = before;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t idx = m[k] & 0x7fffu;
+        if (m[k] & kGlobalColBit) {
+            if (stray_cols && k_stray < kStraySlots) stray_cols[(size_t)sl * kStraySlots + k_stray] = m[k] & ~(kRowEndBit | kGlobalColBit);
+            idx = area + (uint32_t)k_stray++;
+        }
+        out[k] = (uint16_t)(idx | ((m[k] & kRowEndBit) ? kCompactEndBit : 0u));
+    }
+    uint2 q;
+    q.x = (uint32_t)out[0] | ((uint32_t)out[1] << 16); q.y = (uint32_t)out[2] | ((uint32_t)out[3] << 16);
+    ((uint2*)(base + kSliceElems * 4))[t] = q;
+}
+
+int layout_on_device(const uint64_t* d_words, int64_t n_slices, int group_slices, const int32_t* d_groups, int window_floats, int n_waves,
+                     uint8_t* d_bytes, uint32_t* d_stray_cols, void* stream) {
+    if (n_slices <= 0) return 0;
+    hipLaunchKernelGGL(layout_slices_kernel, dim3((unsigned)n_slices), dim3(256), 0, (hipStream_t)stream, d_words, (long long)n_slices, group_slices,
+                       (const int4*)d_groups, window_floats, n_waves, d_bytes, d_stray_cols);
+    return (int)hipGetLastError();
+}
+
 }  // namespace hispmv

@@ -175,7 +175,7 @@ def window_membership(coo_rows, coo_cols, coo_values, rows: int, cols: int, n_cu
     return inside, np.lexsort((np.arange(r.size), c, r))     # stable: duplicates keep their input order, as in coo_to_csr
 
 
-def device_layout_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int, n_cus: int = 256) -> dict:
+def device_layout_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int, n_cus: int = 256, on_device: int = -1) -> dict:
     """The stream of a matrix as the device gets it (hispmv_prep_device_stream), host-only: -> dict with the host words before
     planning (`words`), the plan (`threads`, `group_slices`, `window_floats`, `stray_floats`, `groups`, `frags`) and the device
     arrays (`bytes` u8, `dgroups` [n,4], `stray_cols` [n_slices,64] or empty)."""
@@ -205,7 +205,14 @@ def device_layout_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int,
             return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy() if (n and ptr) else np.zeros(0, dt)
         n_groups = int(dc[1])
         stray_floats = int(dc[4])
-        return dict(words=words, n_slices=n_slices, threads=int(pl[0]), group_slices=int(pl[1]), window_floats=int(dc[5]), stray_floats=stray_floats,
+        extra = {}
+        if on_device >= 0:          # the loader's layout kernel over the same planned words (needs a GPU): bytes_device / stray_cols_device
+            bd = np.zeros(int(dc[0]), np.uint8)
+            sd = np.zeros((n_slices, 64) if stray_floats else (0, 64), np.uint32)
+            if lib.hispmv_prep_device_stream_on_device(p, int(on_device), C.c_void_p(bd.ctypes.data), C.c_void_p(sd.ctypes.data) if stray_floats else None) != HISPMV_OK:
+                raise RuntimeError(lib.hispmv_prep_last_error().decode())
+            extra = dict(bytes_device=bd, stray_cols_device=sd)
+        return dict(**extra, words=words, n_slices=n_slices, threads=int(pl[0]), group_slices=int(pl[1]), window_floats=int(dc[5]), stray_floats=stray_floats,
                     compact_slices=int(dc[2]), stray_slices=int(dc[3]), groups=groups, frags=frags, bytes=arr(0, int(dc[0]), np.uint8),
                     dgroups=arr(1, n_groups * 4, np.int32).reshape(-1, 4),
                     stray_cols=arr(2, n_slices * 64 if stray_floats else 0, np.uint32).reshape(-1, 64))

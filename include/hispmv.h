@@ -237,6 +237,10 @@ const int32_t* hispmv_prep_groups(const hispmv_prep* p);
  * columns (0xffffffff = unused; empty when no group has stray slots).  For tests: the packer without a device. */
 int hispmv_prep_device_stream(hispmv_prep* p, int64_t counts[6]);
 const void* hispmv_prep_device_array(const hispmv_prep* p, int which);
+/* The same layout written on the DEVICE from the planned host words (the kernel hispmv_load_matrices runs with HISPMV_LAYOUT=device):
+ * after hispmv_prep_apply_plan + hispmv_prep_device_stream; bytes_out takes counts[0] bytes, stray_cols_out slices x 64 u32 (may be
+ * NULL when counts[4] == 0).  For tests (device == host, byte for byte); HISPMV_EDEVICE without a GPU. */
+int hispmv_prep_device_stream_on_device(hispmv_prep* p, int device_id, uint8_t* bytes_out, uint32_t* stray_cols_out);
 const int32_t* hispmv_prep_frags(const hispmv_prep* p);
 
 /* Number of device / pinned-memory frees the runtime rejected since the library was loaded (a pointer released twice

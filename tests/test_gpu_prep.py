@@ -101,3 +101,65 @@ def test_soc_pokec_shape_on_the_device_and_through_a_handle(monkeypatch):
         ys.append(y)
         h.close()
     assert np.array_equal(ys[0].view(np.uint32), ys[1].view(np.uint32))
+
+
+def _layout_cases():
+    rng = np.random.default_rng(41)
+    out = {}
+    # a narrow band: LDS windows, every group compact
+    rows = 300000
+    r = np.repeat(np.arange(rows, dtype=np.int64), 14)
+    out["band"] = (r, np.clip(r + rng.integers(-900, 901, r.size), 0, rows - 1), rows, rows)
+    # the same band with 3 % of the entries re-drawn anywhere: compact groups with stray slots (<= 64 strays per slice)
+    c = np.clip(r + rng.integers(-900, 901, r.size), 0, rows - 1)
+    far = rng.random(r.size) < 0.03
+    out["band_strays"] = (r, np.where(far, rng.integers(0, rows, r.size), c), rows, rows)
+    # ... with 12 %: beyond the slots -- wide groups with global-column metas
+    far = rng.random(r.size) < 0.12
+    out["band_many_strays"] = (r, np.where(far, rng.integers(0, rows, r.size), c), rows, rows)
+    # scattered columns: no window at all (wide slices, plain columns), 256-thread plan
+    r2 = rng.integers(0, 50000, 400000)
+    out["scattered"] = (r2, rng.integers(0, 700000, r2.size), 50000, 700000)
+    # long rows (row ends rare, slices cut inside rows) over a small x
+    r3 = rng.integers(0, 300, 900000)
+    out["long_rows"] = (r3, rng.integers(0, 20000, r3.size), 300, 20000)
+    return out
+
+
+@pytest.mark.parametrize("case", ["band", "band_strays", "band_many_strays", "scattered", "long_rows"])
+def test_device_layout_kernel_equals_the_host_packer(case, monkeypatch):
+    """The device layout of a planned slice stream -- compact 6-byte groups, their stray slots and the stray columns behind the headers,
+    wide groups -- written by layout_slices_kernel (what hispmv_load_matrices runs with HISPMV_LAYOUT=device) equals pack_device_stream byte for
+    byte; and a handle loaded with either gives the same y bits."""
+    import pyhispmv
+    from hispmv_amd.prep import device_layout_from_coo
+    r, c, rows, cols = _layout_cases()[case]
+    rng = np.random.default_rng(9)
+    v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
+    monkeypatch.setenv("HISPMV_STRAY_SPLIT", "0")           # (the strays stay in the one stream: slots or wide groups)
+    L = device_layout_from_coo(r.astype(np.int32), c.astype(np.int32), v, rows, cols, on_device=0)
+    assert L["bytes"].size > 0 and np.array_equal(L["bytes"], L["bytes_device"]), case
+    assert np.array_equal(L["stray_cols"], L["stray_cols_device"]), case
+    if case == "band_strays":
+        assert L["stray_floats"] > 0 and L["stray_slices"] > 0 and (L["stray_cols"] != 0xffffffff).any()
+    if case == "band":
+        assert L["compact_slices"] == L["n_slices"]
+    if case in ("scattered",):
+        assert L["compact_slices"] == 0
+    ys = {}
+    x = rng.random(cols, dtype=np.float32) - np.float32(0.3)
+    b = rng.random(rows, dtype=np.float32)
+    monkeypatch.setenv("HISPMV_FORMAT", "slices")
+    for layout in ("device", "host"):
+        monkeypatch.setenv("HISPMV_LAYOUT", layout)
+        h = pyhispmv.FpgaHandle(*HW)
+        idx = h.create_sparse_handle(r.astype(np.int32), c.astype(np.int32), v, rows, cols)
+        h.load_matrices()
+        h.select_matrix(idx)
+        y = np.full(rows, np.nan, np.float32)
+        h.run_kernel(x, b, y, ALPHA, BETA)
+        ys[layout] = (y, h.matrix_info(idx))
+        h.close()
+    assert np.array_equal(ys["device"][0].view(np.uint32), ys["host"][0].view(np.uint32))
+    strip = lambda d: {k: v for k, v in d.items() if k != "prep_seconds"}
+    assert strip(ys["device"][1]) == strip(ys["host"][1])
