@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
         (void)ts;
         {   // the loader's decision, every branch reachable at this size: tile streams from 1 K entries, tiny column tiles, each geometry
             FormatOptions o;
-            o.tts_min_nnz = 1024; o.col_tile_bytes = (t % 2) ? 4096 : (4 << 20); o.format_mode = t % 4 == 3 ? 1 : 2; o.tts_geometry = t % 5; o.decide_only = t % 3 == 0;
+            o.tts_min_nnz = 1024; o.col_tile_bytes = (t % 2) ? 4096 : (4 << 20); o.format_mode = t % 4 == 3 ? 1 : 2; o.tts_geometry = t % 6; o.decide_only = t % 3 == 0;
             Csr copy = m;
             FormatChoice ch = choose_format(std::move(copy), nullptr, t % 2 ? 256 : 8, o);
             if (ch.parts.empty()) { std::puts("choose_format: no parts"); return 1; }
@@ -71,6 +71,21 @@ int main(int argc, char** argv) {
             Csr mb = coo_to_csr(br, br, (long)r2.size(), r2.data(), c2.data(), v2.data());
             FormatChoice ch = choose_format(std::move(mb), nullptr, 256, FormatOptions());
             std::printf("wide band: format %d, tile kind %d, %zu parts\n", ch.format, ch.tile_kind, ch.parts.size());
+        }
+        {   // ... and 1.3 M scattered entries: the sampled "no window can pay" path (no slice stream), the tile-stream packer in the
+            // standard geometry, gap-coded column parts and the shape knob of the column parts
+            const int sr = 400000;
+            std::vector<int32_t> r3, c3; std::vector<float> v3;
+            std::mt19937 g3(11);
+            for (int i = 0; i < sr; ++i) for (int k = 0; k < 3 + (int)(g3() % 2); ++k) { r3.push_back(i); c3.push_back((int)(g3() % 900000)); v3.push_back(0.5f); }
+            for (int variant = 0; variant < 3; ++variant) {
+                Csr ms = coo_to_csr(sr, 900000, (long)r3.size(), r3.data(), c3.data(), v3.data());
+                FormatOptions o;
+                if (variant == 1) o.tts_geometry = 5;
+                if (variant == 2) { o.tts_geometry = 1; o.tall_rows = 8192; o.tall_slots = 28672; o.tall_tiles = 64; o.tall_zero_fill = 0; o.tall_parts = 4; }
+                FormatChoice ch = choose_format(std::move(ms), nullptr, 256, o);
+                std::printf("scattered (variant %d): format %d, %zu parts, %.1f lines per gather\n", variant, ch.format, ch.parts.size(), ch.tts_lines_per_gather);
+            }
         }
         std::printf("stencil: slices %lld, %d threads, %d slices per workgroup, window %d floats\n", (long long)st.n_slices, p.block_threads, p.group_slices, p.lds_floats);
     }
