@@ -235,6 +235,64 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         std::vector<Ref> plain;                                 // parts whose cut rows the fix-up blocks finish
         for (const Ref& r : fixrefs) if (c->mats[idx[r.i]]->parts.size() < 2) plain.push_back(r);
         fused = plain.size() <= (size_t)kMultiMax && tiled.size() <= (size_t)kMultiMax;
+        // HISPMV_LANE_TAILS=1 (experiment, r4_lane_tails.sh): one tail per LANE, enqueued on the lane's own stream right behind its main
+        // launches -- no cross-stream join in front of it -- with the cut rows and merges of the matrices whose parts all ran in that
+        // lane; what is left (a matrix with parts in two lanes) keeps the joined tail.
+        static const bool lane_tails = std::getenv("HISPMV_LANE_TAILS") != nullptr;
+        if (fused && lane_tails && plan.lanes > 1) {
+            auto lane_of_out = [&](const float* out, const SpmvDeviceMatrix* dev) -> int {
+                for (const auto& l : plan.launches) {
+                    if (l.kind == 0) for (const SpmvDeviceMatrix* d : l.parts) if (d == dev) return l.lane;
+                    if (l.kind == 3) for (const TtsEntry& e : l.tts) if (e.y == out) return l.lane;
+                }
+                return -1;
+            };
+            std::vector<std::vector<Ref>> lane_plain((size_t)plan.lanes);
+            std::vector<std::vector<int>> lane_tiled((size_t)plan.lanes);
+            std::vector<Ref> rest_plain; std::vector<int> rest_tiled;
+            for (const Ref& r : plain) { const int ln = lane_of_out(out_of(r), &dev_of(r)); if (ln >= 0) lane_plain[(size_t)ln].push_back(r); else rest_plain.push_back(r); }
+            for (int i : tiled) {
+                Matrix& m = *c->mats[idx[i]];
+                int ln = -2;
+                for (size_t t = 0; t < m.parts.size(); ++t) { const int q = lane_of_out(out_of(Ref{i, t}), &m.parts[t].dev); ln = ln == -2 ? q : (ln == q ? ln : -1); }
+                if (ln >= 0) lane_tiled[(size_t)ln].push_back(i); else rest_tiled.push_back(i);
+            }
+            auto make_tail = [&](const std::vector<Ref>& pl, const std::vector<int>& ti, int lane, bool in_lane) -> int {
+                hispmv_ctx::BatchLaunch l;
+                l.kind = 5; l.lane = lane; l.in_lane = in_lane;
+                std::vector<MultiFixEntry> fix; std::vector<TailMergeEntry> mrg;
+                bool any = !ti.empty();
+                for (const Ref& r : pl) {
+                    SpmvDeviceMatrix& d = dev_of(r);
+                    fix.push_back(MultiFixEntry{d.fix_short, d.carry, out_of(r), d.n_fix_short, 0});
+                    l.fix_counts.push_back(d.n_fix_short);
+                    l.parts.push_back(&d); l.ys.push_back(out_of(r));
+                    any = any || d.n_fix_short > 0 || d.n_fix_long > 0;
+                }
+                for (int i : ti) {
+                    Matrix& m = *c->mats[idx[i]];
+                    TailMergeEntry e{};
+                    e.y = d_y[i]; e.parts = m.d_ypart; e.part_stride = (long long)kMaxBatch * m.rows; e.n_parts = (int32_t)m.parts.size() - 1; e.rows = m.rows;
+                    e.fix_of_row = m.d_fix_of_row;
+                    for (size_t t = 0; t < m.parts.size(); ++t) { e.fix[t] = m.parts[t].dev.fix_short; e.carry[t] = m.parts[t].dev.carry; }
+                    mrg.push_back(e);
+                    l.rows.push_back(m.rows);
+                }
+                if (!any) return HISPMV_OK;
+                plan.launches.push_back(std::move(l));
+                hispmv_ctx::BatchLaunch& L = plan.launches.back();
+                int r2;
+                if (!fix.empty() && (r2 = upload_table(L, fix.data(), fix.size() * sizeof(MultiFixEntry))) != HISPMV_OK) return r2;
+                if (!mrg.empty()) {
+                    HIP_TRY(c, hipMalloc(&L.d_table2, mrg.size() * sizeof(TailMergeEntry)));
+                    HIP_TRY(c, hipMemcpy(L.d_table2, mrg.data(), mrg.size() * sizeof(TailMergeEntry), hipMemcpyHostToDevice));
+                }
+                return HISPMV_OK;
+            };
+            for (int ln = 0; ln < plan.lanes; ++ln)
+                if ((rc = make_tail(lane_plain[(size_t)ln], lane_tiled[(size_t)ln], ln, true)) != HISPMV_OK) return rc;
+            return make_tail(rest_plain, rest_tiled, 0, false);
+        }
         if (fused) {
             hispmv_ctx::BatchLaunch l;
             l.kind = 5;
@@ -368,7 +426,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
         bool joined = lanes <= 1;
         for (const auto& l : plan->launches) {
             hipError_t e = hipSuccess;
-            const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4;
+            const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4 || (l.kind == 5 && l.in_lane);      // (a lane's own tail rides on the lane's stream)
             hipStream_t ls = s;
             if (is_main && lanes > 1) ls = l.lane == 0 ? s : c->side[l.lane - 1];
             if (is_main && c->cu_split) ls = l.kind == 3 ? c->side[1] : c->side[0];

@@ -83,7 +83,8 @@ struct hispmv_ctx {
     int batch_streams = 2;
     int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first
     bool batch_lanes_heavy_first = true;   // HISPMV_BATCH_LANES=rr: plain round-robin lanes
-    bool batch_graphs = true;    // HISPMV_BATCH_GRAPH=0: no HIP graph replay of batch calls
+    bool batch_graphs = false;   // HISPMV_BATCH_GRAPH=1: two-stream batch calls captured into a HIP graph and replayed (the default until round 4;
+                                 //   plain launches measure 1 - 1.5 % faster on the benchmark set: profiles/r4_experiments/graph_vs_plain.json)
     // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
     // the three model_test layers: 49.9 us on one stream, 63.1 on two; the 20-matrix set: 353 -> 344 us with two)
     int64_t batch_streams_min_bytes = 256ll << 20;
@@ -119,6 +120,7 @@ struct hispmv_ctx {
         void* d_table = nullptr;
         void* d_table2 = nullptr;                       // kind 5: the TailMergeEntry table
         int lane = 0;                                   // main launches: 0 = the caller's stream, k > 0 = side stream k - 1
+        bool in_lane = false;                           // kind 5 (HISPMV_LANE_TAILS): the tail of ONE lane's matrices, enqueued on that lane's stream before the join
         int64_t weight = 0;                             // main launches: device bytes of the matrices in the grid
     };
     struct BatchPlan {

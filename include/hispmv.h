@@ -111,7 +111,7 @@ int hispmv_synchronize(hispmv_ctx* ctx);
  * measured with HIP events on the launch stream (milliseconds); negative if unavailable. */
 float hispmv_last_kernel_ms(hispmv_ctx* ctx);
 
-/* Diagnostics of the HIP-graph replay of hispmv_spmv_device_batch: out = {graphs instantiated, alpha patches applied to an
+/* Diagnostics of the HIP-graph replay of hispmv_spmv_device_batch (HISPMV_BATCH_GRAPH=1; plain launches by default): out = {graphs instantiated, alpha patches applied to an
  * instantiated graph}.  A call signature (handles, vectors, beta) is captured and instantiated ONCE; calls that differ only
  * in alpha patch the graph's kernel nodes (hipGraphExecKernelNodeSetParams) instead of instantiating again. */
 int hispmv_batch_graph_stats(hispmv_ctx* ctx, int64_t out[2]);

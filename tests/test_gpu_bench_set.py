@@ -70,11 +70,21 @@ def check_y(name, y, rp, ci, va, cols, x, b, alpha, beta, mkl=True):
     return out
 
 
-def run_set(torch, mats, label):
-    """mats: dicts with rp/ci/va/rows/cols.  One batch call over all of them, then every matrix alone."""
+def run_set(torch, mats, label, graph=False):
+    """mats: dicts with rp/ci/va/rows/cols.  One batch call over all of them, then every matrix alone.  graph: the two-stream batch call
+    replayed as a HIP graph (HISPMV_BATCH_GRAPH=1; plain launches are the default since round 4: 1 - 1.5 % faster on the set)."""
+    import os
     import pyhispmv
     dev = torch.device("cuda", 0)
-    h = pyhispmv.FpgaHandle(*HW)
+    old_env = os.environ.get("HISPMV_BATCH_GRAPH")
+    os.environ["HISPMV_BATCH_GRAPH"] = "1" if graph else "0"
+    try:
+        h = pyhispmv.FpgaHandle(*HW)                 # (the switch is read when the context is created)
+    finally:
+        if old_env is None:
+            del os.environ["HISPMV_BATCH_GRAPH"]
+        else:
+            os.environ["HISPMV_BATCH_GRAPH"] = old_env
     h.set_arena_bytes(64 << 30)
     try:
         for m in mats:
@@ -112,8 +122,12 @@ def run_set(torch, mats, label):
         # change of alpha), and another alpha patches the kernel nodes of the executable that is not in flight (a solver that
         # changes alpha every step must not pay a capture or an instantiation per step)
         st = h.batch_graph_stats()
-        assert st["instantiations"] in (0, 2) and (st["instantiations"] == 0 or st["alpha_updates"] == 1), st
-        if st["instantiations"]:
+        two_lanes = sum(len(m["va"]) for m in mats) * 8 >= (256 << 20)         # (smaller calls stay on one stream: never a graph)
+        if graph and two_lanes:
+            assert st["instantiations"] == 2 and st["alpha_updates"] == 1, st
+        else:
+            assert st["instantiations"] == 0 and st["alpha_updates"] == 0, st
+        if True:
             # the sweep on an explicit stream, NO host synchronisation between the calls, every step's y copied into
             # its own buffer on that stream -- a patch that reached an executable whose earlier launch was still queued would
             # show up as a step computed with its successor's alpha
@@ -134,7 +148,7 @@ def run_set(torch, mats, label):
             st2 = h.batch_graph_stats()
             # (the sweep's stream differs from the earlier calls' NULL stream only in where the graph is launched: same call
             # signature, same executables)
-            assert st2["instantiations"] == 2 and st2["alpha_updates"] == st["alpha_updates"] + 6, st2
+            assert (st2["instantiations"], st2["alpha_updates"]) == ((2, st["alpha_updates"] + 6) if st["instantiations"] else (0, 0)), st2
             # the CALLER captures the call into a graph of its own (bench.py --gpus N captures a rank's whole step): the library
             # must issue plain launches into the capture -- replaying its own graph there recorded nothing -- and the replay
             # must write every y
@@ -149,7 +163,7 @@ def run_set(torch, mats, label):
             torch.cuda.synchronize()
             for m in sorted(mats, key=lambda q: -len(q["va"]))[:4]:
                 check_y(f'{label}:{m["name"]}:batch:caller_graph', m["dy"].cpu().numpy(), m["rp"], m["ci"], m["va"], m["cols"], m["x"], m["b"], ALPHA, BETA, mkl=False)
-            assert h.batch_graph_stats()["instantiations"] == 2
+            assert h.batch_graph_stats()["instantiations"] == st["instantiations"]
             del g
             for m in mats:
                 m["dy"].fill_(float("nan"))
@@ -198,7 +212,7 @@ def test_suitesparse_set_as_benchmarked(torch_mod, family):
         mats = [m for m in mats if m.get("family") == "fem"]
     mats = [m for m in mats if "rp" in m]         # (real files, if a user dropped them in, are covered by the CLI)
     assert mats
-    run_set(torch_mod, mats, family)
+    run_set(torch_mod, mats, family, graph=(family == "structured"))
 
 
 def run_literal(torch, mats, label):
