@@ -867,14 +867,6 @@ def main():
                      "powerlaw": "BASELINE.json configs[2]: R-MAT scale 20 (ef 16, duplicates kept) + Zipf(1.2) row lengths at soc-Pokec's shape",
                      "dense": "dense overlay GeMV, sizes of cpu/run_gemv.sh:9-13 (512..8192 square)",
                      "model": "BASELINE.json configs[3]: apps/model_test.py layers 4096->8192 dense, 8192->8192 d=0.1, 8192->1024 d=0.25, one launch per layer"}
-        # every kernel with >= 10 % of a step's kernel time (profiles/r3_kernel_stats_single_stream.csv)
-        dominant = {"set": "spmv_slices_multi_kernel (two grids per step: the 1024-thread and the 256-thread slice streams) + "
-                           "spmv_tts_multi_kernel (the tile streams: soc-Pokec, nxp1, analytics, boyd2, language); + ONE tail launch per step "
-                           "(spmv_tail_multi_kernel: cut rows of every part + merge of the column-tile partial vectors)"
-                           if args.launch == "batch" else "spmv_slices_kernel / spmv_tts_kernel (+ carry fix-up launches)",
-                    "powerlaw": "spmv_tts_multi_kernel (both matrices are tile streams; + one fix-up launch for the rows cut into pieces)",
-                    "dense": "gemv_rows_multi_kernel",
-                    "model": "gemv_rows_multi_kernel + spmv_slices_multi_kernel + spmv_tts_multi_kernel (one layer each)"}[args.workload]
         classes = {}
         for m in mats:
             info = fpga.matrix_info(m["idx"])
@@ -882,6 +874,14 @@ def main():
                    f"spmv_tts_multi_kernel/{info['block_threads']}t" if info["format"] == 1 else f"spmv_slices_multi_kernel/{info['block_threads']}t")
             cl = classes.setdefault(key, {"matrices": [], "algorithmic_bytes_per_launch": 0, "flops_per_launch": 0})
             cl["matrices"].append(m["name"]); cl["algorithmic_bytes_per_launch"] += int(alg_bytes(m)); cl["flops_per_launch"] += int(flops_of(m))
+        # the kernels of a step, named from what the handles actually are (launch_classes below): one grid per class of a batch call
+        if args.launch == "batch":
+            dominant = " + ".join(f"{k} ({len(v['matrices'])} matri{'x' if len(v['matrices']) == 1 else 'ces'}: {', '.join(v['matrices'][:8])}{', ...' if len(v['matrices']) > 8 else ''})"
+                                  for k, v in classes.items())
+            if any(k.startswith("spmv_") for k in classes):
+                dominant += "; + one spmv_tail_multi_kernel launch per step when rows are cut by slice boundaries or a matrix has column parts"
+        else:
+            dominant = "spmv_slices_kernel / spmv_tts_kernel / gemv_rows_kernel, one launch sequence per matrix (+ carry fix-up launches)"
         out = {
             "metric": {"set": "SpMV GFLOP/s, SuiteSparse set (20 matrices), fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
                        "powerlaw": "SpMV GFLOP/s, power-law matrices, fp32 y=alpha*A*x+beta*y, flops=2*(nnz+rows)",
@@ -897,7 +897,7 @@ def main():
                        "sources": sorted(set(m["source"].split(":")[0] for m in mats)), "standin": args.standin,
                        "alpha": ALPHA, "beta": BETA, "launch": args.launch, "streams": n_streams,
                        "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
-            "ranks_seen": ranks_seen, "backend": backend, "rank_step": getattr(R, "step_mode", "eager" if dist_on else "library graph"),
+            "ranks_seen": ranks_seen, "backend": backend, "rank_step": getattr(R, "step_mode", "eager" if dist_on else ("library graph" if os.environ.get("HISPMV_BATCH_GRAPH", "0") not in ("", "0") else "library launches (two streams, plain)")),
             # every pass over the workload this process issued for the MAIN measurement -- preheat, warm-up, timed steps, the
             # self-check's step, the rank breakdown's eager steps: what a profiler divides its per-kernel totals by
             "passes_over_set": passes_main,
