@@ -33,6 +33,7 @@ class MatrixInfo(C.Structure):
         ("carry_lookback", C.c_int32), ("col_tile_width", C.c_int32),
         ("col_tile_base", C.c_int32), ("compact_slices", C.c_int32),
         ("format", C.c_int32), ("tts_lines_per_gather", C.c_float), ("tile_kind", C.c_int32),
+        ("batch_group_slices", C.c_int32),
     ]
 
 

@@ -94,6 +94,8 @@ int add_sparse(hispmv_ctx* c, Csr&& csr, double t_csr, SliceStream* prebuilt = n
             m->n_slices += p.st.n_slices; m->n_elems += p.st.n_elems; m->n_split += (int64_t)p.st.fix.size();
             m->device_bytes += sparse_device_bytes(p.st, p.dstream) + (int64_t)p.dstream.groups.size() * 4 + (int64_t)p.plan.frags.size() * 16 + (p.dstream.any_stray ? p.st.n_slices * (int64_t)kStraySlots * 4 : 0);
             m->compact_slices += p.dstream.compact_slices;
+            if (p.has_batch_layout) m->device_bytes += p.batch_dstream.n_bytes + (int64_t)p.st.hdr.size() * 16 + (int64_t)p.batch_dstream.groups.size() * 4 + (int64_t)p.batch_plan.frags.size() * 16 +
+                                                       (p.batch_dstream.any_stray ? p.st.n_slices * (int64_t)kStraySlots * 4 : 0);
         }
     }
     if (m->parts.size() > 1) m->device_bytes += (int64_t)(m->parts.size() - 1) * kMaxBatch * m->rows * 4;   // partial vectors of parts t > 0
@@ -607,6 +609,47 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
                 // variant; the look-back variant walks its groups in slice order
                 d.has_strays = p.dstream.stray_floats > 0;
                 if (d.has_strays) { d.lookback = false; d.use_ticket = false; }
+                // the batch layout (hispmv_choose.h): its own group table, fragments, slice bytes and headers (the spill flags differ);
+                // rows, carries, fix lists and the error word are the part's
+                if (p.has_batch_layout) {
+                    SpmvDeviceMatrix b = d;
+                    const int32_t* bg = nullptr; const Frag* bf = nullptr; const uint8_t* bw = nullptr; const SliceHdr* bh = nullptr;
+                    if ((rc = upload(c, m, p.batch_dstream.groups.data(), p.batch_dstream.groups.size(), &bg)) != HISPMV_OK) return rc;
+                    if ((rc = upload(c, m, p.batch_plan.frags.data(), p.batch_plan.frags.size(), &bf)) != HISPMV_OK) return rc;
+                    std::vector<SliceHdr> bhh = hh;
+                    for (int64_t sl = 0; sl < ns; ++sl) bhh[(size_t)sl].x_span = (!p.batch_plan.slice_spills.empty() && p.batch_plan.slice_spills[(size_t)sl]) ? 1 : 0;
+                    uint32_t* b_stray = nullptr;
+                    {
+                        void* blk = nullptr;
+                        const size_t hb = bhh.size() * sizeof(SliceHdr), sb = p.batch_dstream.any_stray ? (size_t)ns * kStraySlots * sizeof(uint32_t) : 0;
+                        HIP_TRY(c, hipMalloc(&blk, hb + sb));
+                        m.allocs.push_back(blk);
+                        HIP_TRY(c, hipMemcpy(blk, bhh.data(), hb, hipMemcpyHostToDevice));            // (`bhh` is a local: synchronous)
+                        if (sb && !p.batch_dstream.stray_cols.empty()) HIP_TRY(c, hipMemcpy((char*)blk + hb, p.batch_dstream.stray_cols.data(), sb, hipMemcpyHostToDevice));
+                        else if (sb) HIP_TRY(c, hipMemsetAsync((char*)blk + hb, 0xff, sb, c->stream));
+                        bh = (const SliceHdr*)blk;
+                        b_stray = sb ? (uint32_t*)((char*)blk + hb) : nullptr;
+                    }
+                    if (!p.batch_dstream.bytes.empty()) {
+                        if ((rc = upload(c, m, p.batch_dstream.bytes.data(), p.batch_dstream.bytes.size(), &bw)) != HISPMV_OK) return rc;
+                    } else {
+                        void* blk = nullptr; uint64_t* tmp = nullptr;
+                        HIP_TRY(c, hipMalloc(&blk, (size_t)p.batch_dstream.n_bytes));
+                        m.allocs.push_back(blk);
+                        bw = (const uint8_t*)blk;
+                        HIP_TRY(c, hipMalloc((void**)&tmp, p.batch_words.size() * sizeof(uint64_t)));
+                        layout_scratch.push_back(tmp);
+                        HIP_TRY(c, hipMemcpyAsync(tmp, p.batch_words.data(), p.batch_words.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                        const int e = layout_on_device(tmp, ns, p.batch_plan.group_slices, bg, p.batch_plan.lds_floats, p.batch_plan.block_threads / 64, (uint8_t*)blk, b_stray, c->stream);
+                        if (e != 0) return hip_fail(c, (hipError_t)e, "layout_on_device");
+                    }
+                    b.words = bw; b.hdr = (const int4*)bh; b.groups = (const int4*)bg; b.frags = (const int4*)bf;
+                    b.group_slices = p.batch_plan.group_slices; b.n_groups = (ns + p.batch_plan.group_slices - 1) / p.batch_plan.group_slices;
+                    b.lds_floats = p.batch_plan.lds_floats + p.batch_dstream.stray_floats;
+                    b.has_strays = p.batch_dstream.stray_floats > 0;
+                    b.lookback = false; b.use_ticket = false;
+                    if ((size_t)(b.lds_floats + b.ytile_floats * (b.block_threads / 64)) * 4 <= 160 * 1024 - 256) { p.batch_dev = b; p.has_batch_dev = true; }
+                }
             }
         }
         if (!m.dense && m.parts.size() > 1) {
@@ -632,7 +675,8 @@ HISPMV_API int hispmv_load_matrices(hispmv_ctx* c) {
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // host copies are no longer needed
-        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; p.plan.frags = {}; p.dstream = DeviceStream{}; }
+        for (auto& p : m.parts) { p.st = SliceStream{}; p.fix_short = {}; p.fix_long = {}; p.plan.groups = {}; p.plan.frags = {}; p.dstream = DeviceStream{};
+                                  p.batch_plan.groups = {}; p.batch_plan.frags = {}; p.batch_plan.slice_spills = {}; p.batch_dstream = DeviceStream{}; p.batch_words = WordVec(); }
         m.dense_host = {};
         m.loaded = true;
     }
@@ -779,6 +823,9 @@ HISPMV_API int hispmv_get_matrix_info(const hispmv_ctx* c, int idx, hispmv_matri
     out->carry_lookback = (!m.dense && !m.parts.empty() && m.parts[0].dev.lookback) ? 1 : 0; out->col_tile_width = m.col_tile_width; out->col_tile_base = m.col_tile_base; out->compact_slices = (int32_t)std::min<int64_t>(m.compact_slices, INT32_MAX);
     out->format = m.format; out->tts_lines_per_gather = (float)m.tts_lines_per_gather;
     out->tile_kind = m.parts.size() > 1 ? (m.tile_kind ? m.tile_kind : 1) : 0;
+    out->batch_group_slices = 0;
+    if (m.parts.size() == 1 && !m.parts[0].is_tts)
+        out->batch_group_slices = m.loaded ? (m.parts[0].has_batch_dev ? m.parts[0].batch_dev.group_slices : 0) : (m.parts[0].has_batch_layout ? m.parts[0].batch_plan.group_slices : 0);
     return HISPMV_OK;
 }
 

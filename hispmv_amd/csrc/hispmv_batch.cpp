@@ -35,7 +35,13 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
     struct Item { std::vector<Ref> refs; int threads; int64_t slices; bool strays = false; };      // strays: a part with stray slots (a grid class of its own)
     std::vector<Item> items;
     std::vector<Ref> refs;
-    auto dev_of = [&](const Ref& r) -> SpmvDeviceMatrix& { return c->mats[idx[r.i]]->parts[r.t].dev; };
+    // (a call that shares the chip between its matrices -- two lanes: at least batch_streams_min_bytes of streams -- takes a part's
+    // BATCH layout where it has one: groups twice as long, hispmv_choose.h)
+    const bool shared_chip = c->batch_streams > 1 && plan.stream_bytes >= c->batch_streams_min_bytes && !std::getenv("HISPMV_NO_BATCH_LAYOUT");
+    auto dev_of = [&](const Ref& r) -> SpmvDeviceMatrix& {
+        Matrix::Part& p = c->mats[idx[r.i]]->parts[r.t];
+        return (shared_chip && p.has_batch_dev) ? p.batch_dev : p.dev;
+    };
     auto out_of = [&](const Ref& r) -> float* {
         Matrix& m = *c->mats[idx[r.i]];
         return r.t == 0 ? d_y[r.i] : m.d_ypart + (r.t - 1) * (size_t)kMaxBatch * m.rows;
@@ -127,7 +133,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             for (size_t t = 0; t < m.parts.size(); ++t) { it.refs.push_back(Ref{i, t}); it.slices += m.parts[t].dev.n_slices; }
             items.push_back(std::move(it));
         } else {
-            for (size_t t = 0; t < m.parts.size(); ++t) items.push_back(Item{{Ref{i, t}}, m.parts[t].dev.block_threads, m.parts[t].dev.n_slices, m.parts[t].dev.has_strays});
+            for (size_t t = 0; t < m.parts.size(); ++t) { const SpmvDeviceMatrix& d = dev_of(Ref{i, t}); items.push_back(Item{{Ref{i, t}}, d.block_threads, d.n_slices, d.has_strays}); }
         }
     }
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) {

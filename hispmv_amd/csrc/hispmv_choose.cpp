@@ -20,6 +20,7 @@ FormatOptions FormatOptions::from_env() {
     if (const char* e = std::getenv("HISPMV_TTS_MIN_NNZ")) o.tts_min_nnz = std::atoll(e);
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
     o.no_stream_skip = std::getenv("HISPMV_NO_STREAM_SKIP") != nullptr;
+    if (const char* e = std::getenv("HISPMV_BATCH_LAYOUT")) o.batch_layout = std::atoi(e) != 0;
     if (const char* e = std::getenv("HISPMV_LAYOUT")) o.device_layout = !std::strcmp(e, "device");
     if (const char* e = std::getenv("HISPMV_TTS_MAX_LINES")) o.tts_max_lines = std::atof(e);
     if (const char* e = std::getenv("HISPMV_TTS_TALL_SHAPE")) std::sscanf(e, "%d,%d,%d,%d,%d", &o.tall_rows, &o.tall_slots, &o.tall_tiles, &o.tall_zero_fill, &o.tall_parts);
@@ -111,6 +112,21 @@ void pack_part(HostPart& p, const FormatOptions& opt) {
     if (!opt.device_layout) p.st.words = WordVec();   // the device layout replaces the host words (else the loader uploads them and lays them out there)
 }
 void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p, n_cus); pack_part(p, opt); }
+
+// The batch layout of a whole-matrix slice stream (HostPart::has_batch_layout): planned for half the CUs, kept when it is the same
+// kind of plan with longer groups.  Call BEFORE pack_part (which may release the words).
+void add_batch_layout(HostPart& p, int n_cus, const FormatOptions& opt) {
+    if (!opt.batch_layout || opt.decide_only || n_cus < 2 || p.plan.lds_floats <= 0 || p.plan.group_slices >= kBatchGroupBelow || p.st.n_slices < 512) return;
+    if (p.plan.group_slices != (p.st.n_slices + (int64_t)n_cus * p.plan.per_cu - 1) / ((int64_t)n_cus * p.plan.per_cu)) return;      // (resident plans only)
+    SliceStream alt = p.st;                       // (headers, fix list, sizes; the words: columns again)
+    alt.words = unplanned_words(p.st, p.plan);
+    LaunchPlan q = make_plan(alt, n_cus / 2);
+    if (q.block_threads != p.plan.block_threads || q.group_slices <= p.plan.group_slices || q.lds_floats <= 0 || q.ytile_floats != p.plan.ytile_floats) return;
+    p.batch_dstream = pack_device_stream(alt, q, !opt.device_layout);
+    if (opt.device_layout) p.batch_words = std::move(alt.words);
+    p.batch_plan = std::move(q);
+    p.has_batch_layout = true;
+}
 
 // "No x window can pay", decided from 32 samples of the CSR instead of from the launch plan of a slice stream: in every sample --
 // 8192 consecutive entries, the elements of the SMALLEST group any plan has (8 slices) -- at least 90 % of the entries sit in a
@@ -471,7 +487,7 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     }
     csr = Csr{};
     lap("column tiles (if any)");
-    if (tw == 0) pack_part(out.parts[0], opt);       // the whole-matrix stream stays: its device layout now
+    if (tw == 0) { add_batch_layout(out.parts[0], n_cus, opt); pack_part(out.parts[0], opt); }       // the whole-matrix stream stays: its device layout(s) now
     lap("device layout");
     return out;
 }

@@ -23,7 +23,18 @@ struct HostPart {
     DeviceStream dstream;                        // the planned stream in its device layout (compact / wide groups)
     bool is_tts = false;
     TtsStream tts;
+    // BATCH LAYOUT (round 4): a second plan and device layout of the same slices with groups twice as long, for batch calls that
+    // share the chip between many matrices.  A resident plan gives a matrix one workgroup per CU; when its groups come out short
+    // (< kBatchGroupBelow slices: nd6k 27, thread 17) a workgroup spends a large part of its life staging its x window, which nothing
+    // hides with one 1024-thread workgroup per CU.  Half as many workgroups of twice the length take 1.2 % off the step of the
+    // benchmark set -- and 20 - 36 % longer when such a matrix runs alone on half the chip, which is why the single launches keep
+    // the first plan (profiles/r4_experiments/group_len.json).  Same slices, same carries, same arithmetic per slice: same bits.
+    bool has_batch_layout = false;
+    LaunchPlan batch_plan;
+    DeviceStream batch_dstream;
+    WordVec batch_words;                         // (device_layout only: the planned host words of the batch layout)
 };
+constexpr int kBatchGroupBelow = 40;
 
 struct FormatOptions {
     int format_mode = 2;          // HISPMV_FORMAT: 0 slices always, 1 tile stream whenever the plan has no window, 2 auto
@@ -41,6 +52,7 @@ struct FormatOptions {
     bool device_layout = false;   // HISPMV_LAYOUT=device: the slice streams keep their 8-byte host words and the loader lays them out on the
                                   //   device (layout_on_device, byte-identical).  Off by default: the upload of the larger words from pageable
                                   //   memory costs more than the host packer saves (set of 20: prep + upload 1.38 s against 1.22 s)
+    bool batch_layout = true;     // HISPMV_BATCH_LAYOUT=0: no second (long-group) layout for batch calls
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
     static FormatOptions from_env();
 };

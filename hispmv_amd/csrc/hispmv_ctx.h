@@ -46,6 +46,8 @@ struct Matrix {
     struct Part : HostPart {                       // host side (hispmv_choose.h; released after upload) + device side
         TtsDeviceMatrix tdev;                      //   of a tile stream
         hispmv::SpmvDeviceMatrix dev;                      //   of a slice stream
+        hispmv::SpmvDeviceMatrix batch_dev;                //   ... in its batch layout (HostPart::has_batch_layout): same slices, headers' rows,
+        bool has_batch_dev = false;                        //       carries and fix lists; its own groups, fragments, slice bytes and spill flags
     };
     std::vector<Part> parts;
     std::vector<float> dense_host;

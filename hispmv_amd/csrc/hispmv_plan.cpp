@@ -369,4 +369,31 @@ DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan, b
     return d;
 }
 
+// The planned words of a part back to columns (make_plan rewrote the column field of staged groups to window indices).
+WordVec unplanned_words(const SliceStream& st, const LaunchPlan& plan) {
+    WordVec w = st.words;
+    const int64_t G = plan.group_slices, n = st.n_slices;
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 16)
+    for (int64_t g = 0; g < (int64_t)plan.groups.size(); ++g) {
+        const GroupDesc& gd = plan.groups[(size_t)g];
+        if (gd.frag_count <= 0) continue;                               // not staged: the words still hold columns
+        const Frag* f0 = plan.frags.data() + gd.frag_begin;
+        const Frag* f1 = f0 + gd.frag_count;
+        const int64_t s0 = g * G, s1 = std::min<int64_t>(n, s0 + G);
+        for (int64_t i = s0 * kSliceElems; i < s1 * kSliceElems; ++i) {
+            const uint32_t m = (uint32_t)(w[(size_t)i] >> 32);
+            uint32_t col;
+            if (m & kGlobalColBit) col = m & ~(kRowEndBit | kGlobalColBit);
+            else {
+                const int32_t idx = (int32_t)(m & ~kRowEndBit);
+                const Frag* it = std::upper_bound(f0, f1, idx, [](int32_t v, const Frag& f) { return v < f.lds_off; }) - 1;
+                col = (uint32_t)(it->col_start + (idx - it->lds_off));
+            }
+            w[(size_t)i] = (w[(size_t)i] & 0x80000000ffffffffull) | ((uint64_t)col << 32);
+        }
+    }
+    return w;
+}
+
+
 }  // namespace hispmv

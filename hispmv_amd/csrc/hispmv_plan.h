@@ -50,6 +50,10 @@ struct LaunchPlan {
 // elements of every LDS-staged group in st.words to the element's index in that group's window.
 LaunchPlan make_plan(SliceStream& st, int n_cus);
 
+// The words of a planned stream with COLUMNS in their meta field again (the inverse of make_plan's rewrite; hispmv_choose.cpp plans a
+// part a second time for its batch layout).
+WordVec unplanned_words(const SliceStream& st, const LaunchPlan& plan);
+
 // LDS floats one wavefront needs for the row totals of a slice (largest number of rows ending in one slice).
 int ytile_floats_for(const SliceStream& st);
 

@@ -175,6 +175,9 @@ typedef struct hispmv_matrix_info {
                                whose band is wider than an LDS window, cut along the diagonal); 3 = STRAY SPLIT: part 0 holds the elements that lie
                                inside the x window of their workgroup (6-byte elements from LDS), part 1 the few per cent that do not (gathered
                                through L2 into a partial vector the tail launch adds); 0 = untiled */
+    int32_t batch_group_slices; /* > 0: the handle also holds a BATCH LAYOUT of its slices -- groups of this many slices (twice group_slices,
+                               half as many workgroups) that hispmv_spmv_device_batch uses when a call shares the chip between its matrices
+                               (two launch lanes); single launches keep group_slices.  0 = none.  Same results bit for bit. */
 } hispmv_matrix_info;
 int hispmv_get_matrix_info(const hispmv_ctx* ctx, int matrix_idx, hispmv_matrix_info* out);
 int hispmv_num_matrices(const hispmv_ctx* ctx);

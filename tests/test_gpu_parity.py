@@ -775,6 +775,63 @@ def test_host_vector_path_direct_and_copied_y(pyhispmv_mod, mode, monkeypatch):
     h.close()
 
 
+def test_batch_layout_of_short_groups(pyhispmv_mod, monkeypatch):
+    """A resident plan whose groups come out short (here 6.9 M entries: 27 slices per workgroup, nd6k's case) gets a second device
+    layout with groups twice as long (hispmv_matrix_info.batch_group_slices) that hispmv_spmv_device_batch takes when the call
+    shares the chip (two lanes: >= 256 MiB of streams -- forced here with HISPMV_BATCH_STREAMS=2); single launches keep the first
+    plan.  Same slices, same carries: the batch call's y equals the single launch's y bit for bit, with the layout on and off, next
+    to a large matrix and a tile stream in the same call."""
+    import torch
+    monkeypatch.setenv("HISPMV_BATCH_STREAMS", "2")
+    rng = np.random.default_rng(21)
+    rows = cols = 18000
+    per = 383                                                     # nd6k's density: 6.9 M entries in a band of +-2500
+    r = np.repeat(np.arange(rows, dtype=np.int64), per)
+    c = np.clip(r + rng.integers(-2500, 2501, r.size), 0, cols - 1).astype(np.int32)
+    r = r.astype(np.int32)
+    v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
+    rows2 = cols2 = 60000                                         # a second, larger slice matrix (groups of > 40 slices: no batch layout)
+    r2 = np.repeat(np.arange(rows2, dtype=np.int64), 300)
+    c2 = np.clip(r2 + rng.integers(-1500, 1501, r2.size), 0, cols2 - 1).astype(np.int32)
+    r2 = r2.astype(np.int32)
+    v2 = rng.random(r2.size, dtype=np.float32) - np.float32(0.5)
+    dev = torch.device("cuda", 0)
+    x, b = rng.random(cols, dtype=np.float32) - np.float32(0.3), rng.random(rows, dtype=np.float32)
+    x2, b2 = rng.random(cols2, dtype=np.float32) - np.float32(0.3), rng.random(rows2, dtype=np.float32)
+    results = {}
+    for layout in ("1", "0"):
+        monkeypatch.setenv("HISPMV_BATCH_LAYOUT", layout)
+        h = pyhispmv_mod.FpgaHandle(*HW)
+        i1 = h.create_sparse_handle(r, c, v, rows, cols)
+        i2 = h.create_sparse_handle(r2, c2, v2, rows2, cols2)
+        h.load_matrices()
+        info1, info2 = h.matrix_info(i1), h.matrix_info(i2)
+        assert info1["block_threads"] == 1024 and info1["group_slices"] < 40 and info1["lds_bytes"] > 0, info1
+        assert info1["batch_group_slices"] == (2 * info1["group_slices"] if layout == "1" else 0) or \
+               (layout == "1" and abs(info1["batch_group_slices"] - 2 * info1["group_slices"]) <= 2), info1
+        assert info2["batch_group_slices"] == 0 and info2["group_slices"] >= 40, info2
+        dx, db, dx2, db2 = (torch.from_numpy(a).to(dev) for a in (x, b, x2, b2))
+        dy = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev)
+        dy2 = torch.full((rows2,), float("nan"), dtype=torch.float32, device=dev)
+        h.spmv_device(i1, dx.data_ptr(), db.data_ptr(), dy.data_ptr(), ALPHA, BETA, None)
+        h.synchronize()
+        single = dy.cpu().numpy().copy()
+        batch = h.prepare_batch([i2, i1], [dx2.data_ptr(), dx.data_ptr()], [db2.data_ptr(), db.data_ptr()], [dy2.data_ptr(), dy.data_ptr()])
+        for _ in range(2):
+            dy.fill_(float("nan")); dy2.fill_(float("nan"))
+            torch.cuda.synchronize()
+            h.spmv_device_batch(batch, ALPHA, BETA, None)
+            h.synchronize()
+            assert np.array_equal(dy.cpu().numpy().view(np.uint32), single.view(np.uint32)), layout
+        P = prepared_tiles(info1, r, c, v, rows, cols)[0]
+        y64, mag = oracle.spmv_f64(P.row_ptr.astype(np.int32), P.col_idx, P.values, x, b, ALPHA, BETA)
+        assert bwd_err(single, y64, mag) < TOL
+        results[layout] = (single, dy2.cpu().numpy().copy())
+        h.close()
+    assert np.array_equal(results["1"][0].view(np.uint32), results["0"][0].view(np.uint32))
+    assert np.array_equal(results["1"][1].view(np.uint32), results["0"][1].view(np.uint32))
+
+
 def test_wide_band_is_cut_along_the_diagonal(fpga):
     """Band tiles (hispmv_matrix_info.tile_kind 2): a banded matrix whose band (+-24000 here) is wider than an LDS window is cut
     into ranges of the offset from the diagonal; every part then runs with its x window in LDS and 6-byte elements.  Bitwise

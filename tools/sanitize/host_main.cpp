@@ -33,7 +33,10 @@ int main(int argc, char** argv) {
         }
         Csr m = coo_to_csr(rows, cols, nnz, r.data(), c.data(), v.data());
         SliceStream st = build_stream(m);
-        for (int cus : {256, 8, 1}) { SliceStream copy = st; LaunchPlan p = make_plan(copy, cus); DeviceStream d = pack_device_stream(copy, p); (void)d; }
+        for (int cus : {256, 8, 1}) {
+            SliceStream copy = st; LaunchPlan p = make_plan(copy, cus); DeviceStream d = pack_device_stream(copy, p); (void)d;
+            if (unplanned_words(copy, p) != st.words) { std::puts("unplanned_words: not the inverse of make_plan"); return 1; }
+        }
         TtsStream ts = build_tts(m, t % 3 == 0 ? 5000 : 0);                      // the second device format
         (void)ts;
         {   // the loader's decision, every branch reachable at this size: tile streams from 1 K entries, tiny column tiles, each geometry
@@ -62,7 +65,18 @@ int main(int argc, char** argv) {
             for (int k = 0; k < per; ++k) { r.push_back(i); c.push_back((i + (k * 37) % 3000) % rows); v.push_back(1.f); }
         Csr m = coo_to_csr(rows, rows, (long)r.size(), r.data(), c.data(), v.data());
         SliceStream st = build_stream(m);
+        const WordVec before = st.words;
         LaunchPlan p = make_plan(st, 256);
+        if (unplanned_words(st, p) != before) { std::puts("unplanned_words: not the inverse of make_plan (stencil)"); return 1; }
+        {   // the loader's decision with the batch layout of short groups (6 M entries: 23 slices per workgroup on 256 CUs)
+            std::vector<int32_t> rh, ch2; std::vector<float> vh;
+            for (int i = 0; i < rows; ++i) for (int k = 0; k < per / 2; ++k) { rh.push_back(i); ch2.push_back((i + (k * 37) % 3000) % rows); vh.push_back(1.f); }
+            Csr mc = coo_to_csr(rows, rows, (long)rh.size(), rh.data(), ch2.data(), vh.data());
+            FormatOptions o;
+            FormatChoice ch = choose_format(std::move(mc), nullptr, 256, o);
+            std::printf("stencil through choose_format: %d threads, %d slices per workgroup, batch layout %s (%d slices per workgroup)\n", ch.parts[0].plan.block_threads,
+                        ch.parts[0].plan.group_slices, ch.parts[0].has_batch_layout ? "yes" : "no", ch.parts[0].has_batch_layout ? ch.parts[0].batch_plan.group_slices : 0);
+        }
         {   // ... and a wide unstructured band of 5 M entries: the band-tile branch
             const int br = 250000, bper = 20, half = 30000;
             std::vector<int32_t> r2, c2; std::vector<float> v2;
