@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256) void gather_lane(const uint32_t* __restrict__ 
     if (acc == 123.456f) out[wave] = acc;
 }
 
+// the lane gather through a buffer descriptor with the cache-policy bits of the instruction (AUX: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x/gfx950)
+template <int AUX>
+__global__ __launch_bounds__(256) void gather_lane_aux(const uint32_t* __restrict__ cols, const float* __restrict__ x,
+                                                       float* __restrict__ out, long long n_groups, unsigned table_bytes) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long g0 = wave * kGroupsPerWave;
+    if (g0 >= n_groups) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)table_bytes, 0x00020000);
+    uint32_t c[kGroupsPerWave];
+#pragma unroll
+    for (int g = 0; g < kGroupsPerWave; ++g) c[g] = cols[(g0 + g) * 64 + lane];
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroupsPerWave; ++g) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, c[g] << 2, 0, AUX));
+    if (acc == 123.456f) out[wave] = acc;
+}
+
 // the same gathers with the table cut in two halves: workgroups of XCDs 0-3 (blockIdx mod 8 < 4) read the lower half, the others the
 // upper half -- what pinning the column parts of a tile stream to XCD subsets is meant to buy (an XCD's L2 holds half of x)
 __global__ __launch_bounds__(256) void gather_lane_halves(const uint32_t* __restrict__ cols, const float* __restrict__ x,
@@ -157,6 +175,8 @@ int main(int argc, char** argv) {
                sum_lines / n_groups, sum_lines64 / n_groups, max_lines, NI);
         dim3 grid((unsigned)((n_groups / kGroupsPerWave + 3) / 4)), blk(256);
         run("lane (dword gather)", [&] { hipLaunchKernelGGL(gather_lane, grid, blk, 0, 0, d_cols, d_x, d_out, n_groups); });
+#define AUXRUN(A) run("lane, buffer load aux " #A, [&] { hipLaunchKernelGGL((gather_lane_aux<A>), grid, blk, 0, 0, d_cols, d_x, d_out, n_groups, (unsigned)(table_floats * 4)); });
+        AUXRUN(0) AUXRUN(1) AUXRUN(2) AUXRUN(3) AUXRUN(16) AUXRUN(17) AUXRUN(18)
         run("lane, halves by XCD", [&] { hipLaunchKernelGGL(gather_lane_halves, grid, blk, 0, 0, d_cols, d_x, d_out, n_groups, (uint32_t)(table_floats / 2), 1); });
         run("lane, halves not by XCD", [&] { hipLaunchKernelGGL(gather_lane_halves, grid, blk, 0, 0, d_cols, d_x, d_out, n_groups, (uint32_t)(table_floats / 2), 0); });
 #define LINE(N) \
