@@ -31,6 +31,42 @@
 namespace hispmv {
 
 // ---------------------------------------------------------------------------
+// Workgroup trace (diagnostic builds only: make WGTRACE=1 -> libhispmv_wgtrace.so; the product library carries none of it).
+// Every workgroup of the multi-matrix kernels records {start, end} on the 100 MHz constant clock, the CU it ran on
+// (XCC_ID, HW_ID) and what it was (kernel kind, table entry, group / tile): tools/wg_timeline.py turns the records of one
+// step into per-CU occupancy -- how much of a step a CU spends inside workgroups, and in which kind.
+// ---------------------------------------------------------------------------
+#ifdef HISPMV_WG_TRACE
+__device__ unsigned long long* g_wgt_buf = nullptr;     // [0] = record counter, records of 4 x u64 from [4]
+__device__ unsigned g_wgt_cap = 0;
+struct WgTrace {
+    unsigned long long t0;
+    __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void end(int kind, int entry, long long item) {
+        __syncthreads();
+        if (threadIdx.x == 0 && g_wgt_buf) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned long long i = __hip_atomic_fetch_add(g_wgt_buf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < g_wgt_cap) {
+                unsigned long long* r = g_wgt_buf + 4 + 4 * i;
+                r[0] = t0; r[1] = t1;
+                r[2] = ((unsigned long long)xcc << 32) | hw;
+                r[3] = ((unsigned long long)kind << 56) | ((unsigned long long)(entry & 0xffff) << 40) | (unsigned long long)(item & 0xffffffffffll);
+            }
+        }
+    }
+};
+#define WGT_BEGIN() WgTrace wgt; wgt.begin()
+#define WGT_END(kind, entry, item) wgt.end(kind, entry, item)
+#else
+#define WGT_BEGIN()
+#define WGT_END(kind, entry, item)
+#endif
+
+// ---------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
@@ -700,6 +736,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntr
     }
     const MultiEntry t = table[e];
     if (group * t.group_slices >= t.n_slices) return;      // (a pinned tile with fewer groups than its siblings)
+    WGT_BEGIN();
     const LookbackArgs lb{};
     // beta is per entry: the first column tile of a matrix applies beta*bias, its other tiles write alpha*A_t*x into the
     // handle's partial vectors (no bias read) -- both kinds share the grid, a workgroup runs one of the two bodies
@@ -709,6 +746,7 @@ __global__ __launch_bounds__(1024) void spmv_slices_multi_kernel(const MultiEntr
     else
         slices_body<false, true, false, STRAYS>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, alpha, 0.0f,
                                         t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group);
+    WGT_END(blockDim.x == 1024 ? 1 : 2, e, group);
 }
 
 // Fix-up of all matrices of a multi launch: thread blocks are concatenated the same way.
@@ -1593,8 +1631,10 @@ __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __
     }
     const TtsEntry e = table[entry];      // (once per workgroup; every load in the body is cast to the global address space)
     if (tile >= e.m.n_tiles) return;      // (a part with fewer tiles than its sibling)
+    WGT_BEGIN();
     if (e.beta != 0.0f) tts_tile_body<true, ZERO_FILL, 1, XLDS, GAP>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
     else tts_tile_body<false, ZERO_FILL, 1, XLDS, GAP>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
+    WGT_END(3, entry, tile);
 }
 
 template <int NV, bool XLDS>
@@ -1961,3 +2001,13 @@ hipError_t launch_boundary_apply(float* const* first, const float* recv, const f
 }
 
 }  // namespace hispmv
+
+#ifdef HISPMV_WG_TRACE
+// Diagnostic builds only (see WgTrace above): hand the kernels a device buffer of 4 + 4*cap u64 (zeroed by the caller), or NULL.
+extern "C" __attribute__((visibility("default"))) int hispmv_wg_trace_set(void* buf, unsigned cap) {
+    unsigned long long* p = (unsigned long long*)buf;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hispmv::g_wgt_buf), &p, sizeof(p)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hispmv::g_wgt_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+#endif
