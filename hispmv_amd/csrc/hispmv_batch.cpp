@@ -18,7 +18,7 @@ void free_batch_plans(hispmv_ctx* c) {
             g.launched = false;
         }
         if (p.graph_src) { (void)hipGraphDestroy(p.graph_src); p.graph_src = nullptr; }
-        for (auto& l : p.launches) { dev_free(l.d_table); dev_free(l.d_table2); }
+        for (auto& l : p.launches) { dev_free(l.d_table); dev_free(l.d_table2); dev_free(l.d_items); dev_free(l.d_sync); }
     }
     c->batch_plans.clear();
 }
@@ -170,6 +170,7 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
             l.item_tiles.push_back((uint8_t)items[k].refs.size());
             ++k;
         }
+        l.multi = entries;
         plan.launches.push_back(std::move(l));
         if ((rc = upload_table(plan.launches.back(), entries.data(), entries.size() * sizeof(MultiEntry))) != HISPMV_OK) return rc;
     }
@@ -188,6 +189,157 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
         plan.launches.clear();
         for (auto& l : slices) plan.launches.push_back(std::move(l));
         for (auto& l : rest) plan.launches.push_back(std::move(l));
+    }
+    // The step kernel: when the call shares the chip between its matrices and every main launch is a slice grid (1024- or 256-thread
+    // plans, no XCD-pinned column tiles) or a tile-stream grid of the standard geometry, the main launches collapse into ONE launch
+    // whose items -- a 1024-thread group, four 256-thread groups, a tile -- are drawn from a queue by one persistent workgroup per CU
+    // (hispmv_kernels.hip: spmv_step_kernel; per-CU occupancy before / after: profiles/r4_experiments/wg_timeline.json).
+    if (c->step_kernel && shared_chip && !c->cu_split && !c->batch_graphs) {
+        bool ok = true;
+        size_t lds = 0;
+        bool strays = false;
+        for (const auto& l : plan.launches) {
+            if (l.kind == 4) ok = false;
+            if (l.kind == 0) {
+                for (uint8_t t : l.item_tiles) ok = ok && t == 1;
+                for (const SpmvDeviceMatrix* d : l.parts) {
+                    ok = ok && (d->block_threads == 1024 || d->block_threads == 256);
+                    const size_t one = ((size_t)d->lds_floats + (size_t)d->ytile_floats * (d->block_threads / 64)) * sizeof(float);
+                    lds = std::max(lds, d->block_threads == 256 ? 4 * one : one);
+                    strays = strays || d->has_strays;
+                }
+            }
+            if (l.kind == 3) {
+                for (uint8_t t : l.item_tiles) ok = ok && t == 1;
+                for (const TtsEntry& e : l.tts) {
+                    ok = ok && e.m.zero_fill == 0 && e.m.threads == 1024 && !tts_x_in_lds(e.m, 1);
+                    lds = std::max(lds, tts_tile_lds_bytes(e.m));
+                }
+            }
+        }
+        ok = ok && lds <= 160 * 1024 - 256;
+        if (ok) {
+            struct QItem { uint32_t a, b; double cost; int cls; };      // cls 0 = slice items, 1 = tiles
+            std::vector<QItem> q[2];
+            std::vector<MultiEntry> slice_table;
+            std::vector<TtsEntry> tts_table;
+            double compact_frac_of[1] = {0};
+            (void)compact_frac_of;
+            for (const auto& l : plan.launches) {
+                if (l.kind == 0) {
+                    for (size_t e = 0; e < l.multi.size(); ++e) {
+                        const SpmvDeviceMatrix& d = *l.parts[e];
+                        const uint32_t entry = (uint32_t)slice_table.size();
+                        slice_table.push_back(l.multi[e]);
+                        const int64_t ng = d.n_slices > 0 ? d.n_groups : 0;
+                        // cost of a group in "microseconds of a CU": 0.27 us per compact 6 KiB slice read from an LDS window (measured: 32.7 ms of
+                        // CU time for the 1024-thread groups of the set), 2.5-fold for groups that gather through L2; + the window staging
+                        const bool window = d.lds_floats > 0;
+                        const double per_slice = window ? 0.27 : 0.68;
+                        if (d.block_threads == 1024) {
+                            for (int64_t g = 0; g < ng; ++g) {
+                                const int64_t n_here = std::min<int64_t>(d.group_slices, d.n_slices - g * d.group_slices);
+                                q[0].push_back(QItem{0u | (entry << 8), (uint32_t)g, 1.0 + per_slice * (double)n_here + (double)d.lds_floats * 4.0 / 40000.0, 0});
+                            }
+                        } else {
+                            for (int64_t g = 0; g < ng; g += 4) {
+                                const int64_t n_here = std::min<int64_t>(d.group_slices, d.n_slices - g * d.group_slices);
+                                // (four groups side by side, each gathering through L2 or from a small window: 10 - 20 us measured; priced so that
+                                // they sort AHEAD of the 11 - 16 us groups of the smallest 1024-thread plans -- at the very end of the queue, where
+                                // only a few CUs come free at a time, they stretched the step by 10 us)
+                                static const double f256 = std::getenv("HISPMV_STEP_COST256") ? std::atof(std::getenv("HISPMV_STEP_COST256")) : 8.0;
+                                q[0].push_back(QItem{1u | (entry << 8), (uint32_t)g, 1.0 + f256 * (double)n_here + (double)d.lds_floats * 4.0 / 40000.0, 0});
+                            }
+                        }
+                    }
+                }
+                if (l.kind == 3) {
+                    for (const TtsEntry& te : l.tts) {
+                        const uint32_t entry = (uint32_t)tts_table.size();
+                        tts_table.push_back(te);
+                        // the slices of every tile, from the device tables (the host copies are gone after the upload)
+                        std::vector<int4> tiles((size_t)te.m.n_tiles);
+                        HIP_TRY(c, hipMemcpy(tiles.data(), te.m.tiles, tiles.size() * sizeof(int4), hipMemcpyDeviceToHost));
+                        int n_blocks = 0;
+                        for (const int4& t : tiles) n_blocks = std::max(n_blocks, t.z + t.w);
+                        std::vector<int4> blocks((size_t)n_blocks * 2);
+                        if (n_blocks > 0) HIP_TRY(c, hipMemcpy(blocks.data(), te.m.blocks, blocks.size() * sizeof(int4), hipMemcpyDeviceToHost));
+                        // 0.85 us per 1024-element slice with 23 lines of x per gather (soc-Pokec), scaled by the line model of DESIGN.md 2.2
+                        double lines = 23.0;
+                        for (int i = 0; i < n; ++i) { const Matrix& m = *c->mats[idx[i]]; if (!m.dense && m.format == 1 && m.parts[0].tdev.words == te.m.words && m.tts_lines_per_gather > 0) lines = m.tts_lines_per_gather; }
+                        const double per_slice = 0.85 * (50.0 + 2.8 * lines) / (50.0 + 2.8 * 23.0);
+                        for (int t = 0; t < te.m.n_tiles; ++t) {
+                            int64_t sl = 0;
+                            for (int b = tiles[(size_t)t].z; b < tiles[(size_t)t].z + tiles[(size_t)t].w; ++b) sl += blocks[(size_t)b * 2].y;
+                            q[1].push_back(QItem{2u | (entry << 8), (uint32_t)t, 2.0 + per_slice * (double)sl + 0.5 * (double)tiles[(size_t)t].w, 1});
+                        }
+                    }
+                }
+            }
+            if (slice_table.size() < (1u << 20) && tts_table.size() < (1u << 20) && q[0].size() + q[1].size() > 0) {
+                std::vector<QItem> order;
+                const int W = std::max(1, c->n_cus);
+                if (c->step_order == 2) {            // the order of the grids: tiles, 1024-thread groups, 256-thread groups (as the launches were)
+                    for (const QItem& it : q[1]) order.push_back(it);
+                    for (const QItem& it : q[0]) order.push_back(it);
+                } else {
+                    for (auto& v : q) std::stable_sort(v.begin(), v.end(), [](const QItem& x, const QItem& y) { return x.cost > y.cost; });
+                    double total[2] = {0, 0}, done[2] = {0, 0};
+                    for (int k = 0; k < 2; ++k) for (const QItem& it : q[k]) total[k] += it.cost;
+                    const double T = (total[0] + total[1]) / W;      // the step if nothing idles
+                    size_t pos[2] = {0, 0};
+                    while (pos[0] < q[0].size() || pos[1] < q[1].size()) {
+                        int k;
+                        if (pos[0] >= q[0].size()) k = 1;
+                        else if (pos[1] >= q[1].size()) k = 0;
+                        else if (c->step_order == 1) k = q[1][pos[1]].cost > q[0][pos[0]].cost ? 1 : 0;       // longest first
+                        else {
+                            // the LONG tiles (more than a quarter of the step: soc-Pokec's) alternate with the longest slice groups, so that
+                            // the cache-bound tiles and the HBM-bound groups start side by side on different CUs and every long tile has
+                            // started within the first third of the step; behind them: longest first
+                            const bool long_tile = q[1][pos[1]].cost > 0.25 * T;
+                            if (long_tile) k = (pos[0] + pos[1]) % 2 == 0 ? 1 : 0;
+                            else k = q[1][pos[1]].cost > q[0][pos[0]].cost ? 1 : 0;
+                        }
+                        order.push_back(q[k][pos[k]]);
+                        done[k] += q[k][pos[k]].cost;
+                        ++pos[k];
+                    }
+                }
+                std::vector<uint32_t> packed;
+                packed.reserve(order.size() * 2);
+                for (const QItem& it : order) { packed.push_back(it.a); packed.push_back(it.b); }
+                hispmv_ctx::BatchLaunch L;
+                L.kind = 6;
+                L.n_items = (unsigned)order.size();
+                L.step_workgroups = (int)std::min<size_t>((size_t)W, order.size());
+                L.step_lds = lds;
+                L.step_strays = strays;
+                for (const auto& l : plan.launches) L.weight += l.weight;
+                // the launches it replaces go; their device tables with them
+                std::vector<hispmv_ctx::BatchLaunch> keep;
+                for (auto& l : plan.launches) {
+                    if (l.kind == 0 || l.kind == 3) { dev_free(l.d_table); dev_free(l.d_table2); }
+                    else keep.push_back(std::move(l));
+                }
+                plan.launches.clear();
+                plan.launches.push_back(std::move(L));
+                for (auto& l : keep) plan.launches.push_back(std::move(l));
+                hispmv_ctx::BatchLaunch& S = plan.launches.front();
+                if (!slice_table.empty()) {
+                    HIP_TRY(c, hipMalloc(&S.d_table, slice_table.size() * sizeof(MultiEntry)));
+                    HIP_TRY(c, hipMemcpy(S.d_table, slice_table.data(), slice_table.size() * sizeof(MultiEntry), hipMemcpyHostToDevice));
+                }
+                if (!tts_table.empty()) {
+                    HIP_TRY(c, hipMalloc(&S.d_table2, tts_table.size() * sizeof(TtsEntry)));
+                    HIP_TRY(c, hipMemcpy(S.d_table2, tts_table.data(), tts_table.size() * sizeof(TtsEntry), hipMemcpyHostToDevice));
+                }
+                HIP_TRY(c, hipMalloc(&S.d_items, packed.size() * sizeof(uint32_t)));
+                HIP_TRY(c, hipMemcpy(S.d_items, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIP_TRY(c, hipMalloc((void**)&S.d_sync, 2 * sizeof(unsigned)));
+                HIP_TRY(c, hipMemset(S.d_sync, 0, 2 * sizeof(unsigned)));
+            }
+        }
     }
     std::vector<Ref> fixrefs = refs;                            // + tile streams that cut long rows into pieces
     for (int i = 0; i < n; ++i) {
@@ -413,7 +565,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
         }
         const int rc = build_batch_plan(c, c->batch_plans.back(), n, idx, d_x, bias, d_y, beta);
         if (rc != HISPMV_OK) {                                      // nothing half-built stays behind
-            for (auto& l : c->batch_plans.back().launches) { dev_free(l.d_table); dev_free(l.d_table2); }
+            for (auto& l : c->batch_plans.back().launches) { dev_free(l.d_table); dev_free(l.d_table2); dev_free(l.d_items); dev_free(l.d_sync); }
             c->batch_plans.pop_back();
             return rc;
         }
@@ -432,7 +584,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
         bool joined = lanes <= 1;
         for (const auto& l : plan->launches) {
             hipError_t e = hipSuccess;
-            const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4 || (l.kind == 5 && l.in_lane);      // (a lane's own tail rides on the lane's stream)
+            const bool is_main = l.kind == 0 || l.kind == 3 || l.kind == 4 || l.kind == 6 || (l.kind == 5 && l.in_lane);      // (a lane's own tail rides on the lane's stream)
             hipStream_t ls = s;
             if (is_main && lanes > 1) ls = l.lane == 0 ? s : c->side[l.lane - 1];
             if (is_main && c->cu_split) ls = l.kind == 3 ? c->side[1] : c->side[0];
@@ -442,6 +594,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
             }
             if (l.kind == 0) e = launch_spmv_multi(l.parts.data(), (int)l.parts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const MultiEntry*)l.d_table, alpha, ls);
             else if (l.kind == 3) e = launch_tts_multi(l.tts.data(), (int)l.tts.size(), l.item_tiles.data(), (int)l.item_tiles.size(), (const TtsEntry*)l.d_table, alpha, ls);
+            else if (l.kind == 6) e = launch_spmv_step((const MultiEntry*)l.d_table, (const TtsEntry*)l.d_table2, l.d_items, l.n_items, l.d_sync, l.step_workgroups, l.step_lds, l.step_strays, alpha, ls);
             else if (l.kind == 4) e = launch_gemv_multi(l.gemv.data(), (int)l.gemv.size(), (const GemvEntry*)l.d_table, alpha, ls);
             else if (l.kind == 1) e = launch_fixup_multi(l.parts.data(), l.ys.data(), (int)l.parts.size(), (const MultiFixEntry*)l.d_table, alpha, ls);
             else if (l.kind == 5) {
@@ -451,7 +604,7 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
                     if (l.parts[q]->n_fix_long > 0) e = launch_fixup_long(*l.parts[q], l.ys[q], alpha, ls);
             }
             else e = launch_merge_multi(l.rows.data(), (int)l.rows.size(), (const MultiMergeEntry*)l.d_table, ls);
-            if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : l.kind == 5 ? "launch_tail_multi" : "launch_merge_multi");
+            if (e != hipSuccess) return hip_fail(c, e, l.kind == 0 ? "launch_spmv_multi" : l.kind == 1 ? "launch_fixup_multi" : l.kind == 3 ? "launch_tts_multi" : l.kind == 4 ? "launch_gemv_multi" : l.kind == 6 ? "launch_spmv_step" : l.kind == 5 ? "launch_tail_multi" : "launch_merge_multi");
         }
         if (!joined)
             for (int i = 0; i + 1 < lanes; ++i) { HIP_TRY(c, hipEventRecord(c->ev_join[i], c->side[i])); HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }

@@ -85,6 +85,10 @@ struct hispmv_ctx {
     int batch_streams = 2;
     int batch_order = 0;         // HISPMV_BATCH_ORDER: 0 tile streams first (default), 1 small slice grids first
     bool batch_lanes_heavy_first = true;   // HISPMV_BATCH_LANES=rr: plain round-robin lanes
+    // The step kernel (hispmv_kernels.h: launch_spmv_step): a call that shares the chip between its matrices runs all its slice groups
+    // and tiles as items of ONE queue drawn by one persistent workgroup per CU.  HISPMV_STEP_KERNEL=0: the grids of rounds 1 - 4 on two lanes.
+    bool step_kernel = true;
+    int step_order = 0;          // HISPMV_STEP_ORDER: 0 = kinds mixed in proportion, long items first (default); 1 = longest first (lpt); 2 = grid order
     bool batch_graphs = false;   // HISPMV_BATCH_GRAPH=1: two-stream batch calls captured into a HIP graph and replayed (the default until round 4;
                                  //   plain launches measure 1 - 1.5 % faster on the benchmark set: profiles/r4_experiments/graph_vs_plain.json)
     // ... for calls that stream at least this much: forking to and joining from a side stream costs ~13 us (measured on
@@ -111,7 +115,7 @@ struct hispmv_ctx {
     // tables, built on the first call and replayed afterwards
     struct BatchLaunch {
         int kind = 0;                                   // 0 slice kernels of one workgroup size, 1 fix-up of cut rows, 2 merge of column-tile
-                                                        // partial vectors, 3 transposed tile streams, 4 dense overlay (GeMV)
+                                                        // partial vectors, 3 transposed tile streams, 4 dense overlay (GeMV), 5 tail, 6 step kernel
         std::vector<hispmv::TtsEntry> tts;                      // kind 3
         std::vector<hispmv::GemvEntry> gemv;                    // kind 4: the dense overlay handles of the call in one grid
         std::vector<const hispmv::SpmvDeviceMatrix*> parts;     // kinds 0, 1
@@ -119,8 +123,16 @@ struct hispmv_ctx {
         std::vector<int32_t> rows;                      // kind 2
         std::vector<uint8_t> item_tiles;                // kind 0: parts per item (> 1: the XCD-pinned column tiles of one matrix)
         std::vector<int32_t> fix_counts;                // kind 5 (fix-up + merge in one launch): short fix entries per part; rows = merged matrices
+        std::vector<hispmv::MultiEntry> multi;                  // kind 0: host copy of the table (the step kernel's table is the concatenation)
         void* d_table = nullptr;
-        void* d_table2 = nullptr;                       // kind 5: the TailMergeEntry table
+        void* d_table2 = nullptr;                       // kind 5: the TailMergeEntry table; kind 6: the TtsEntry table
+        // kind 6 (the step kernel, hispmv_kernels.h: launch_spmv_step): every slice group and every tile of the call as items of one queue
+        void* d_items = nullptr;                        //   n_items x {kind | entry << 8, index}, in queue order
+        unsigned* d_sync = nullptr;                     //   ticket + exit counter (zeroed once; the kernel rearms them)
+        unsigned n_items = 0;
+        int step_workgroups = 0;
+        size_t step_lds = 0;
+        bool step_strays = false;
         int lane = 0;                                   // main launches: 0 = the caller's stream, k > 0 = side stream k - 1
         bool in_lane = false;                           // kind 5 (HISPMV_LANE_TAILS): the tail of ONE lane's matrices, enqueued on that lane's stream before the join
         int64_t weight = 0;                             // main launches: device bytes of the matrices in the grid

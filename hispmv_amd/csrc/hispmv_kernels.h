@@ -165,6 +165,16 @@ hipError_t launch_tts_batched(const TtsDeviceMatrix& m, int nv, const float* x, 
 hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_parts, int n_items, const TtsEntry* d_table, float alpha,
                             hipStream_t stream);
 
+// The step kernel (hispmv_kernels.hip: spmv_step_kernel): every slice group and every tile of a batch call as ITEMS of one queue,
+// drawn by `workgroups` persistent 1024-thread workgroups.  d_items: n_items x {kind | table entry << 8, index}:
+// kind 0 = group `index` of slice_table[entry] (a 1024-thread plan), 1 = groups index .. index + 3 of a 256-thread plan, 2 = tile
+// `index` of tts_table[entry] (standard geometry, x gathered through the cache).  d_sync: two zeroed words the kernel rearms itself.
+// `strays`: some slice part has stray slots.
+struct StepArgs { const MultiEntry* slice_table; const TtsEntry* tts_table; const int2* items; unsigned* sync; unsigned n_items; float alpha; int stagger, ticket_word; };
+hipError_t launch_spmv_step(const MultiEntry* d_slice_table, const TtsEntry* d_tts_table, const void* d_items, unsigned n_items,
+                            unsigned* d_sync, int workgroups, size_t lds_bytes, bool strays, float alpha, hipStream_t stream);
+size_t tts_tile_lds_bytes(const TtsDeviceMatrix& m);
+
 // Dense overlay: y = alpha*W*x + beta*bias, W row-major rows x cols.
 hipError_t launch_gemv(const float* W, int32_t rows, int32_t cols, const float* x, const float* bias,
                        float* y, float alpha, float beta, hipStream_t stream);

@@ -329,6 +329,14 @@ __device__ __forceinline__ void stage_fragments(const int4* __restrict__ frags, 
     }
 }
 
+// Which wavefronts of the workgroup work on a group, and where its LDS begins: the whole workgroup for the slice kernels; in
+// the step kernel (below) a 1024-thread workgroup hosts FOUR groups of a 256-thread plan side by side, four wavefronts each.
+struct SubBlock {
+    int wave, n_waves, lds_off;       // this wavefront's index among the group's wavefronts, their number, first LDS float of the group
+    int lane;                         // (handed in: the step kernel makes the thread index opaque per item, see there)
+    static __device__ __forceinline__ SubBlock whole() { return SubBlock{(int)(threadIdx.x >> 6), (int)(blockDim.x >> 6), 0, (int)(threadIdx.x & 63)}; }
+};
+
 // The work of one workgroup on group `group` of a matrix (the body of the slice kernels below), for a group stored
 // COMPACT (6 B per element) or wide (8 B): two instantiations, chosen per group by slices_body.
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool COMPACT, bool STRAYS = false>
@@ -337,9 +345,10 @@ __device__ __forceinline__ void slices_group(
     const int4* __restrict__ frags,
     const float* __restrict__ x, const float* bias, float* y,   // bias may alias y
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group, int4 g) {
+    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group, int4 g, const SubBlock sb) {
     // LDS: [x window: lds_floats][row totals of the slice in flight: ytile_floats per wavefront]
-    extern __shared__ float xs[];
+    extern __shared__ float xs_base[];
+    float* const xs = xs_base + sb.lds_off;
     // x, bias and y are reached through buffer descriptors: 32-bit byte offsets instead of 64-bit
     // addresses (half the address VGPRs, one shift per gather), and the hardware range check turns an
     // offset of 0xffffffff into "no access" -- the predicate of the bias loads and y stores costs no branch,
@@ -350,11 +359,11 @@ __device__ __forceinline__ void slices_group(
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)carry, 0, LOOKBACK ? 0 : (int)(n_slices * 4), 0x00020000);
     constexpr unsigned kNoAccess = 0xffffffffu;
     constexpr int kE = kSliceSteps * kLaneElems;     // elements of a slice per lane (16)
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int lane = sb.lane;
+    const int wave = sb.wave, n_waves = sb.n_waves;
     float* const ytile = xs + (USE_LDS ? lds_floats : 0) + wave * ytile_floats;
     // look-back mailbox of the group: one {carry, launch tag} per slice, published by the wavefront that owns it
-    lds_u64* const mbox = (lds_u64*)(xs + (USE_LDS ? lds_floats : 0) + (blockDim.x >> 6) * ytile_floats);
+    lds_u64* const mbox = (lds_u64*)(xs + (USE_LDS ? lds_floats : 0) + n_waves * ytile_floats);
     const long long first = group * group_slices;
     const long long last = (first + group_slices < n_slices) ? first + group_slices : n_slices;   // exclusive
     // where the group's slices lie in the stream: the group table says so for staged plans; a plan without windows is
@@ -674,7 +683,7 @@ __device__ __forceinline__ void slices_body(
     const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
     const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
     float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
-    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group) {
+    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group, const SubBlock sb) {
     __shared__ long long s_group;
     if (LOOKBACK) {
         // Groups are handed out in START order (one ticket per workgroup), so every slice a wavefront
@@ -691,17 +700,27 @@ __device__ __forceinline__ void slices_body(
         }
     }
     if constexpr (USE_LDS) {
-        const int4 g = load_int4(groups + group);     // {first fragment, fragments, offset of the group's slices, compact}
+        // (a sub-block of the step kernel past the matrix's last group: an empty group -- it only joins the barrier)
+        const int4 g = group * group_slices < n_slices ? load_int4(groups + group) : int4{0, 0, 0, 0};     // {first fragment, fragments, offset of the group's slices, compact}
         if (__builtin_amdgcn_readfirstlane(g.w) != 0)
             slices_group<HAS_BETA, true, LOOKBACK, true, STRAYS>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
-                                                         lds_floats, ytile_floats, cols, rows, lb, group, g);
+                                                         lds_floats, ytile_floats, cols, rows, lb, group, g, sb);
         else
             slices_group<HAS_BETA, true, LOOKBACK, false>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
-                                                          lds_floats, ytile_floats, cols, rows, lb, group, g);
+                                                          lds_floats, ytile_floats, cols, rows, lb, group, g, sb);
     } else {
         slices_group<HAS_BETA, false, LOOKBACK, false>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
-                                                       lds_floats, ytile_floats, cols, rows, lb, group, int4{0, 0, 0, 0});
+                                                       lds_floats, ytile_floats, cols, rows, lb, group, int4{0, 0, 0, 0}, sb);
     }
+}
+template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool STRAYS = false>
+__device__ __forceinline__ void slices_body(
+    const char* __restrict__ stream, const int4* __restrict__ hdr, const int4* __restrict__ groups,
+    const int4* __restrict__ frags, const float* __restrict__ x, const float* bias, float* y,
+    float* __restrict__ carry, float alpha, float beta, long long n_slices, int group_slices,
+    int lds_floats, int ytile_floats, int cols, int rows, const LookbackArgs& lb, long long group) {
+    slices_body<HAS_BETA, USE_LDS, LOOKBACK, STRAYS>(stream, hdr, groups, frags, x, bias, y, carry, alpha, beta, n_slices, group_slices,
+                                                     lds_floats, ytile_floats, cols, rows, lb, group, SubBlock::whole());
 }
 
 template <bool HAS_BETA, bool USE_LDS, bool LOOKBACK, bool STRAYS = false>
@@ -1338,14 +1357,14 @@ __device__ __forceinline__ void tts_request(TtsSlice& s, const char* words, int 
 // apps/model_test.py (1024 x 8192).  Staging areas are sized by the matrix's largest block (batch_stage_floats), as for NV > 1.
 template <bool HAS_BETA, bool ZERO_FILL = false, int NV = 1, bool XLDS = false, bool GAP = false>
 __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const float* __restrict__ x, const float* bias, float* y,
-                                              float alpha, float beta, int tile_index) {
+                                              float alpha, float beta, int tile_index, const unsigned tid) {
     extern __shared__ float xs[];
     float* const acc0 = xs;
     float* const staging0 = xs + M.acc_floats * NV;
     const int stage_stride = (NV > 1 || XLDS) ? M.batch_stage_floats : M.staging_floats;
     float* const tails = staging0 + stage_stride * NV;
     float* const xw0 = tails + 64 * NV;                      // XLDS: NV copies of x, xlds_floats apart
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform: table reads become scalar loads
     const int n_waves = blockDim.x >> 6;
     constexpr int kE = kSliceSteps * kLaneElems;
@@ -1366,7 +1385,7 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
-        for (int i = threadIdx.x; i < n_rows; i += blockDim.x) acc0[v * M.acc_floats + i] = 0.0f;
+        for (int i = tid; i < n_rows; i += blockDim.x) acc0[v * M.acc_floats + i] = 0.0f;
     if (XLDS) {
         // all loads of a thread in flight, then the LDS writes (a load-store loop waited out one L2 round trip per 1024 floats)
         const HISPMV_GLOBAL float* xg = (const HISPMV_GLOBAL float*)x;
@@ -1374,16 +1393,16 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
         for (int v = 0; v < NV; ++v) {
             float t[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) { const int i = (int)threadIdx.x + u * (int)blockDim.x; t[u] = i < M.cols ? xg[(size_t)v * M.cols + i] : 0.0f; }
+            for (int u = 0; u < kU; ++u) { const int i = (int)tid + u * (int)blockDim.x; t[u] = i < M.cols ? xg[(size_t)v * M.cols + i] : 0.0f; }
 #pragma unroll
-            for (int u = 0; u < kU; ++u) { const int i = (int)threadIdx.x + u * (int)blockDim.x; if (i < M.xlds_floats) xw0[v * M.xlds_floats + i] = t[u]; }
+            for (int u = 0; u < kU; ++u) { const int i = (int)tid + u * (int)blockDim.x; if (i < M.xlds_floats) xw0[v * M.xlds_floats + i] = t[u]; }
         }
     }
     // zero-fill geometry (hispmv_tts.h): rows absent from a block own a slot of its row-major order but no stream word --
     // the staging is all zero whenever a phase A starts: zeroed here, and phase B writes zeros back over what it has read
     // (a template parameter: as a run-time flag its zero vector lived across the block loop and the multi-matrix kernel spilled)
     if (ZERO_FILL)
-        for (int i = threadIdx.x; i < ((stage_stride * NV) >> 2); i += blockDim.x) ((float4*)staging0)[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = tid; i < ((stage_stride * NV) >> 2); i += blockDim.x) ((float4*)staging0)[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
 
     // phase A for one slice: gathers, products -> staging, the request that reuses the buffer (next >= 0)
@@ -1567,14 +1586,14 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
     }
     __syncthreads();
     if (row0 < 0) {         // a piece of a long row: its raw sum waits in carry[] for the fix-up launch (vector v: carry + v * n_carry)
-        if ((int)threadIdx.x < NV) *(HISPMV_GLOBAL float*)(M.carry + (size_t)threadIdx.x * M.n_carry + (-row0 - 1)) = acc0[threadIdx.x * M.acc_floats];
+        if ((int)tid < NV) *(HISPMV_GLOBAL float*)(M.carry + (size_t)tid * M.n_carry + (-row0 - 1)) = acc0[tid * M.acc_floats];
         return;
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const float* const acc = acc0 + v * M.acc_floats;
         float* const yv = y + (size_t)v * M.rows;
-        for (int i = threadIdx.x; i < n_rows; i += blockDim.x) {
+        for (int i = tid; i < n_rows; i += blockDim.x) {
             const float t = acc[i];
             if (HAS_BETA) *(HISPMV_GLOBAL float*)(yv + row0 + i) = alpha * t + beta * *(const HISPMV_GLOBAL float*)(bias + row0 + i);
             else *(HISPMV_GLOBAL float*)(yv + row0 + i) = alpha * t;
@@ -1583,6 +1602,11 @@ __device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const fl
 }
 
 // NV vectors per pass over the words (tts_tile_body<., ., NV>), x through the cache or from the LDS
+template <bool HAS_BETA, bool ZERO_FILL = false, int NV = 1, bool XLDS = false, bool GAP = false>
+__device__ __forceinline__ void tts_tile_body(const TtsDeviceMatrix& M, const float* __restrict__ x, const float* bias, float* y,
+                                              float alpha, float beta, int tile_index) {
+    tts_tile_body<HAS_BETA, ZERO_FILL, NV, XLDS, GAP>(M, x, bias, y, alpha, beta, tile_index, threadIdx.x);
+}
 template <bool HAS_BETA, int NV, bool XLDS>
 __global__ __launch_bounds__(1024) void spmv_tts_nv_kernel(TtsDeviceMatrix M, const float* __restrict__ x, const float* bias, float* y,
                                                            float alpha, float beta) {
@@ -1635,6 +1659,119 @@ __global__ __launch_bounds__(1024) void spmv_tts_multi_kernel(const TtsEntry* __
     if (e.beta != 0.0f) tts_tile_body<true, ZERO_FILL, 1, XLDS, GAP>(e.m, e.x, e.bias, e.y, alpha, e.beta, tile);
     else tts_tile_body<false, ZERO_FILL, 1, XLDS, GAP>(e.m, e.x, e.y, e.y, alpha, 0.0f, tile);
     WGT_END(3, entry, tile);
+}
+
+// A wave-uniform table read through the CONSTANT address space (dword by dword: scalar loads).
+template <class T>
+__device__ __forceinline__ T load_const(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized tables");
+    typedef const __attribute__((address_space(4))) unsigned* CP;
+    union U { T t; unsigned w[sizeof(T) / 4]; __device__ U() {} } u;
+    CP src = (CP)(const void*)p;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) u.w[i] = src[i];
+    return u.t;
+}
+
+// ---------------------------------------------------------------------------
+// The step kernel: ALL main work of a batch call -- slice groups of every workgroup size and tiles of every tile stream -- in
+// ONE launch of one persistent 1024-thread workgroup per CU that draws ITEMS from a queue (a ticket counter in device memory)
+// until the queue is empty.  An item = one group of a 1024-thread plan, FOUR consecutive groups of a 256-thread plan (four
+// wavefronts each, their LDS side by side: SubBlock), or one tile.  Every item runs the very body of the multi-matrix kernels
+// above (same instantiations, same arithmetic: same bits); what changes is who hands out the work:
+//   * the dispatcher needs 1.4 - 3.4 us to replace a finished workgroup by the next (tools/wg_timeline.py: 7.6 changes per CU and
+//     step, 15 us of every CU's 282) -- here the next item's ticket is drawn while the current item runs, a change costs a barrier;
+//   * the queue is ordered by the host (longest items first, kinds mixed: hispmv_batch.cpp), so the step ends with short items
+//     instead of with whatever the last grid's tail happens to be (9.4 us of idle per CU at the end of a step before);
+//   * one launch on the caller's stream: no fork to / join from a side stream in front of the tail launch.
+// The last workgroup to leave resets the counters (self-cleaning: graph replays and plain launches alike, no host state).
+// ---------------------------------------------------------------------------
+template <bool STRAYS>        // some slice part of the call has stray slots: the instantiation that fetches them (it serves parts without them too)
+__global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
+    // the ticket's LDS word: the LAST four bytes of the dynamic LDS, behind everything the items use.  (As a static __shared__ variable
+    // it was placed FIRST and pushed the dynamic LDS to offset 4: every 16-byte LDS access of the bodies -- window staging, the tiles'
+    // ds_read_b128 -- became misaligned and the tiles ran 10 % slower than in the grids.)
+    extern __shared__ float step_lds[];
+    unsigned& s_next = *(unsigned*)(step_lds + args.ticket_word);
+    if (threadIdx.x == 0) s_next = __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+#pragma unroll 1
+    for (;;) {
+        // Nothing of the queue lives in registers across an item (the tile body runs at the 128-VGPR ceiling of a 1024-thread
+        // workgroup and within two SGPRs of theirs: loop state carried across it spilled 187 SGPRs and 12 VGPRs to scratch):
+        // the arguments are read again from the kernel-argument segment at the top of every item (scalar loads that hit the
+        // constant cache) and the ticket travels through the LDS.
+        typedef const __attribute__((address_space(4))) StepArgs* KernArgs;
+        KernArgs ap = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        const StepArgs a{ap->slice_table, ap->tts_table, ap->items, ap->sync, ap->n_items, ap->alpha, ap->stagger, ap->ticket_word};
+        unsigned& s_next = *(unsigned*)(step_lds + a.ticket_word);
+        const unsigned it = s_next;
+        if (it >= a.n_items) break;
+        __syncthreads();                    // every thread has read the ticket: its slot may take the next one
+        const int2 item = load_const(a.items + __builtin_amdgcn_readfirstlane((int)it));
+        const unsigned kind = (unsigned)__builtin_amdgcn_readfirstlane(item.x) & 3u;
+        const int entry = (int)((unsigned)__builtin_amdgcn_readfirstlane(item.x) >> 8);
+        const long long index = (long long)(unsigned)__builtin_amdgcn_readfirstlane(item.y);
+        // the thread index, opaque per item: everything the bodies derive from it (lane offsets, masks) would otherwise be
+        // hoisted out of this loop, held across the items and -- at the tile body's register ceiling -- spilled to scratch, with
+        // the reloads (and their vmcnt(0)) right behind the slice requests
+        unsigned tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+        WGT_BEGIN();
+#ifndef STEP_NO_TTS
+        if (kind == 2) {
+            // a tile: the next ticket is drawn and parked in the LDS BEFORE the tile starts (no register to hold it across the
+            // body); thread 0's wavefront issues its first requests a memory round trip late, the other fifteen do not
+            if (tid == 0) s_next = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (experiment, StepArgs::stagger > 0: tiles that start in the same instant march through their streams in lockstep;
+            // a delay of 0 .. stagger-1 quanta of ~0.2 us by tile index takes them out of step)
+            for (int q = (int)((unsigned)index * 37u % (unsigned)(a.stagger > 0 ? a.stagger : 1)); q > 0; --q) __builtin_amdgcn_s_sleep(8);
+            // (the tables through the CONSTANT address space: scalar loads -- as generic pointers read from memory they became
+            // flat loads into some forty VGPRs)
+            const TtsEntry e = load_const(a.tts_table + entry);
+            if (e.beta != 0.0f) tts_tile_body<true>(e.m, e.x, e.bias, e.y, a.alpha, e.beta, (int)index, tid);
+            else tts_tile_body<false>(e.m, e.x, e.y, e.y, a.alpha, 0.0f, (int)index, tid);
+        } else
+#endif
+#ifndef STEP_NO_SLICES
+        {
+            // slice groups (91 - 97 VGPRs): the next ticket is in flight while the item runs and is consumed behind it
+            unsigned next = 0;
+            if (tid == 0) next = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const MultiEntry t = load_const(a.slice_table + entry);
+            const LookbackArgs lb{};
+            // kind 0: the workgroup is the group's; kind 1: four groups of a 256-thread plan, wavefronts 4q .. 4q+3 take group index + q
+            const SubBlock sb = kind == 0 ? SubBlock{wave, 16, 0, (int)(tid & 63)} : SubBlock{wave & 3, 4, (wave >> 2) * (t.lds_floats + 4 * t.ytile_floats), (int)(tid & 63)};
+            const long long group = kind == 0 ? index : index + (wave >> 2);
+            if (t.beta != 0.0f)
+                slices_body<true, true, false, STRAYS>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.bias, t.y, t.carry, a.alpha, t.beta,
+                                                       t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group, sb);
+            else
+                slices_body<false, true, false, STRAYS>((const char*)t.words, t.hdr, t.groups, t.frags, t.x, t.y, t.y, t.carry, a.alpha, 0.0f,
+                                                        t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group, sb);
+            if (tid == 0) s_next = next;
+        }
+#else
+        {}
+#endif
+        // the item's LDS is free and the next ticket visible behind this barrier
+#ifdef HISPMV_WG_TRACE
+        WGT_END(kind == 2 ? 3 : kind == 0 ? 1 : 2, entry, index);        // (contains the barrier)
+#else
+        __syncthreads();
+#endif
+    }
+    // every workgroup draws exactly one ticket past the end; the last one out rearms the queue for the next launch
+    if (threadIdx.x == 0) {
+        unsigned* const sync = ((const __attribute__((address_space(4))) StepArgs*)__builtin_amdgcn_kernarg_segment_ptr())->sync;
+        const unsigned done = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <int NV, bool XLDS>
@@ -1778,6 +1915,30 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
     else if (g > 0) hipLaunchKernelGGL(spmv_tts_multi_kernel<false>, dim3((unsigned)g), dim3(entries[0].m.threads), lds, stream, d_table, px, alpha);
     return hipGetLastError();
 }
+
+hipError_t launch_spmv_step(const MultiEntry* d_slice_table, const TtsEntry* d_tts_table, const void* d_items, unsigned n_items,
+                            unsigned* d_sync, int workgroups, size_t lds_bytes, bool strays, float alpha, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_items == 0) return hipSuccess;
+    if (workgroups <= 0 || lds_bytes > 160 * 1024 - 256) return hipErrorInvalidValue;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)spmv_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        raised = true;
+    }
+    static const int stagger = std::getenv("HISPMV_STEP_STAGGER") ? std::atoi(std::getenv("HISPMV_STEP_STAGGER")) : 0;
+    // (+ 16 bytes behind the items' LDS for the ticket word)
+    const size_t ticket_byte = (lds_bytes + 15) & ~(size_t)15;
+    lds_bytes = ticket_byte + 16;
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const StepArgs a{d_slice_table, d_tts_table, (const int2*)d_items, d_sync, n_items, alpha, stagger, (int)(ticket_byte / 4)};
+    if (strays) hipLaunchKernelGGL(spmv_step_kernel<true>, dim3((unsigned)workgroups), dim3(1024), lds_bytes, stream, a);
+    else hipLaunchKernelGGL(spmv_step_kernel<false>, dim3((unsigned)workgroups), dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+size_t tts_tile_lds_bytes(const TtsDeviceMatrix& m) { return tts_lds_bytes(m); }
 
 // ---------------------------------------------------------------------------
 // Dense overlay (reference: ComputeAB dense branch base_functions.cpp:188-226, packing
