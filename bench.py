@@ -672,6 +672,12 @@ def main():
 
     preheat_ms = R.preheat(step, args.preheat)
     t_wall, t_dev = R.time_steps(step, args.steps, args.warmup)
+    main_call_info = None            # how the library issued the step just timed (before the sub-measurements issue theirs)
+    if args.launch == "batch":
+        try:
+            main_call_info = fpga.batch_call_info()
+        except Exception:
+            main_call_info = None
     # self-check (outside the timed region): one more step, every rank's y against a host fp64 product of its shard
     y_err, y_rows, y_skipped = (R.verify(mats, step) if not args.no_verify else (None, 0, len(mats)))
     # True / False when rows were checked; None when nothing was checkable (--no-verify, or no host CSR for any matrix): skipped,
@@ -874,8 +880,15 @@ def main():
                    f"spmv_tts_multi_kernel/{info['block_threads']}t" if info["format"] == 1 else f"spmv_slices_multi_kernel/{info['block_threads']}t")
             cl = classes.setdefault(key, {"matrices": [], "algorithmic_bytes_per_launch": 0, "flops_per_launch": 0})
             cl["matrices"].append(m["name"]); cl["algorithmic_bytes_per_launch"] += int(alg_bytes(m)); cl["flops_per_launch"] += int(flops_of(m))
-        # the kernels of a step, named from what the handles actually are (launch_classes below): one grid per class of a batch call
-        if args.launch == "batch":
+        # the kernels of a step, named from what the handles actually are (launch_classes below): one grid per class of a batch call --
+        # or, when the call shares the chip between its matrices, ONE spmv_step_kernel launch whose queue holds the groups and tiles of
+        # all classes (the library says which: hispmv_batch_call_info)
+        call_info = main_call_info
+        if call_info and call_info["step_kernel"]:
+            dominant = (f"spmv_step_kernel (ONE launch per step: {call_info['items']} items -- slice groups and tiles of all {len(mats)} matrices -- drawn from a queue "
+                        "by one persistent 1024-thread workgroup per CU; the classes it replaces: " + ", ".join(f"{k} ({len(v['matrices'])})" for k, v in classes.items())
+                        + "); + one spmv_tail_multi_kernel launch per step (cut rows, merge of column-tile partial vectors)")
+        elif args.launch == "batch":
             dominant = " + ".join(f"{k} ({len(v['matrices'])} matri{'x' if len(v['matrices']) == 1 else 'ces'}: {', '.join(v['matrices'][:8])}{', ...' if len(v['matrices']) > 8 else ''})"
                                   for k, v in classes.items())
             if any(k.startswith("spmv_") for k in classes):
@@ -897,7 +910,9 @@ def main():
                        "sources": sorted(set(m["source"].split(":")[0] for m in mats)), "standin": args.standin,
                        "alpha": ALPHA, "beta": BETA, "launch": args.launch, "streams": n_streams,
                        "parallelism": f"nnz-split x{world}" if world > 1 else "single GPU"},
-            "ranks_seen": ranks_seen, "backend": backend, "rank_step": getattr(R, "step_mode", "eager" if dist_on else ("library graph" if os.environ.get("HISPMV_BATCH_GRAPH", "0") not in ("", "0") else "library launches (two streams, plain)")),
+            "ranks_seen": ranks_seen, "backend": backend, "rank_step": getattr(R, "step_mode", "eager" if dist_on else ("library graph" if os.environ.get("HISPMV_BATCH_GRAPH", "0") not in ("", "0") else
+                                                     "library launches (step kernel + tail, one stream)" if (call_info and call_info["step_kernel"]) else "library launches (two streams, plain)")),
+            "batch_call": call_info,
             # every pass over the workload this process issued for the MAIN measurement -- preheat, warm-up, timed steps, the
             # self-check's step, the rank breakdown's eager steps: what a profiler divides its per-kernel totals by
             "passes_over_set": passes_main,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "hispmv_synchronize": (C.c_int, [_p]),
     "hispmv_last_kernel_ms": (C.c_float, [_p]),
     "hispmv_batch_graph_stats": (C.c_int, [_p, C.POINTER(C.c_int64)]),
+    "hispmv_batch_call_info": (C.c_int, [_p, C.POINTER(C.c_int64)]),
     "hispmv_spmv_device_batch": (C.c_int, [_p, C.c_int32, _p, _p, _p, _p, C.c_float, C.c_float, _p]),
     "hispmv_time_device": (C.c_float, [_p, C.c_int, _p, _p, _p, C.c_float, C.c_float, C.c_int]),
     "hispmv_get_matrix_info": (C.c_int, [_p, C.c_int, C.POINTER(MatrixInfo)]),

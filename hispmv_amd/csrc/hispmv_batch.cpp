@@ -571,6 +571,12 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
         }
         plan = &c->batch_plans.back();
     }
+    {
+        int64_t step_items = 0;
+        for (const auto& l : plan->launches) if (l.kind == 6) step_items += l.n_items;
+        c->last_batch[0] = (int64_t)plan->launches.size(); c->last_batch[1] = step_items > 0; c->last_batch[2] = step_items;
+        c->last_batch[3] = c->cu_split ? 3 : plan->lanes;
+    }
     // main launches (kinds 0 and 3) are independent of each other: spread over the caller's stream and the side streams;
     // the fix-up and merge launches follow on the caller's stream behind a join
     const int lanes = c->cu_split ? 3 : plan->lanes;
@@ -686,6 +692,14 @@ int spmv_batch_locked(hispmv_ctx* c, int32_t n, const int32_t* idx, const float*
     return enqueue();
 }
 }  // namespace hispmv
+
+HISPMV_API int hispmv_batch_call_info(hispmv_ctx* c, int64_t out[4]) {
+    if (!c || !out) return HISPMV_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->last_batch[0] < 0) return fail(c, HISPMV_ESTATE, "no batch call yet");
+    for (int i = 0; i < 4; ++i) out[i] = c->last_batch[i];
+    return HISPMV_OK;
+}
 
 HISPMV_API int hispmv_batch_graph_stats(hispmv_ctx* c, int64_t out[2]) {
     if (!c || !out) return HISPMV_EINVAL;

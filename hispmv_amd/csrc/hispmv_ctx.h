@@ -160,6 +160,7 @@ struct hispmv_ctx {
     };
     std::vector<BatchPlan> batch_plans;
     int64_t graph_instantiations = 0, graph_alpha_updates = 0;     // hispmv_batch_graph_stats
+    int64_t last_batch[4] = {-1, 0, 0, 0};                          // hispmv_batch_call_info
     // Rows shared between slices: "fixup" = second tiny launch, "lookback" = single launch with carry
     // granules, "auto" (default) = look-back without ticket when the whole grid is co-resident (small
     // matrices, where the extra launch costs as much as the kernel), fix-up otherwise.

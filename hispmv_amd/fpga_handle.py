@@ -217,3 +217,11 @@ class FpgaHandle:
         out = (C.c_int64 * 2)()
         self._check(lib.hispmv_batch_graph_stats(self._ctx, out))
         return {"instantiations": int(out[0]), "alpha_updates": int(out[1])}
+
+    def batch_call_info(self) -> dict:
+        """How the last spmv_device_batch call was issued (hispmv_batch_call_info): launches, whether its slice groups and tiles
+        ran as items of the step kernel's queue, the items, the HIP streams of the main launches."""
+        import ctypes as C
+        out = (C.c_int64 * 4)()
+        self._check(lib.hispmv_batch_call_info(self._ctx, out))
+        return {"launches": int(out[0]), "step_kernel": bool(out[1]), "items": int(out[2]), "streams": int(out[3])}

@@ -115,6 +115,11 @@ float hispmv_last_kernel_ms(hispmv_ctx* ctx);
  * instantiated graph}.  A call signature (handles, vectors, beta) is captured and instantiated ONCE; calls that differ only
  * in alpha patch the graph's kernel nodes (hipGraphExecKernelNodeSetParams) instead of instantiating again. */
 int hispmv_batch_graph_stats(hispmv_ctx* ctx, int64_t out[2]);
+/* How the LAST hispmv_spmv_device_batch call of this context was issued (diagnostics; bench.py names the kernels of its step from
+ * it): out = {launches of the call, 1 if its slice groups and tiles ran as items of the step kernel's queue (one persistent
+ * workgroup per CU, hispmv_kernels.hip: spmv_step_kernel), items of that queue, HIP streams the main launches were spread over}.
+ * HISPMV_ESTATE before the first batch call. */
+int hispmv_batch_call_info(hispmv_ctx* ctx, int64_t out[4]);
 
 /* n independent SpMVs y_i = alpha*A_i*x_i + beta*bias_i on loaded handles idx[i] in as few launches as possible: the
  * workgroups of all matrices with the same workgroup size share ONE grid (plus one fix-up launch), so small matrices no

@@ -49,7 +49,7 @@ if trace:
     for s0, e0, name in ev:
         if start is None:
             start = s0
-        if "merge_multi" in name:
+        if "merge_multi" in name or "tail_multi" in name:
             spans.append((e0 - start) / 1e3)
             start = None
     if spans:
@@ -58,6 +58,33 @@ if trace:
                 f"{sum(tail) / len(tail):.1f} us on average (min {min(tail):.1f}); under the profiler the chip clocks lower than in an "
                 "un-profiled run (MI355X_MICROARCH.md, DVFS), bench.py's HIP-event time is the un-profiled figure.", ""]
 
+
+# The step kernel (the default path of a call that shares the chip between its matrices): ONE launch holds the slice groups and tiles of
+# every class, so its algorithmic bytes are the whole step's (sum over bench.py's launch_classes) and its average duration in the main
+# trace gives the dominant kernel's roofline fraction directly.
+step_kernel_row = None
+if trace:
+    classes_main = {}
+    try:
+        for line in (src / "trace.log").read_text().splitlines():
+            if line.startswith("{") and "launch_classes" in line:
+                classes_main = json.loads(line)["launch_classes"]
+    except Exception:
+        pass
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace)) if "spmv_step_kernel" in r["Kernel_Name"]]
+    if d and classes_main:
+        tail = d[-30:]
+        avg = sum(tail) / len(tail)
+        ab = sum(v["algorithmic_bytes_per_launch"] for k, v in classes_main.items() if k.startswith("spmv_"))
+        step_kernel_row = {"kernel": "spmv_step_kernel", "workgroup": 1024, "launches_averaged": len(tail), "avg_us": round(avg, 2), "min_us": round(min(tail), 2),
+                           "matrices": sum((v["matrices"] for k, v in classes_main.items() if k.startswith("spmv_")), []), "algorithmic_bytes_per_launch": ab,
+                           "achieved_gbs": round(ab / avg / 1e3, 1), "frac_of_8TBs": round(ab / avg / 1e3 / 8000.0, 4)}
+        (dst / f"{tag}_step_kernel_roofline.json").write_text(json.dumps({"method": "main kernel trace (default path), last 30 launches of spmv_step_kernel; algorithmic bytes = sum over "
+                                                                                     "bench.py launch_classes (8*nnz+16*rows+4 per matrix); peak 8 TB/s", "kernel": step_kernel_row}, indent=1) + "\n")
+        out += ["## The step kernel (default path, main trace, last 30 steps)", "",
+                f"`spmv_step_kernel`: {avg:.2f} us per launch on average (min {min(tail):.2f}) for {ab / 1e6:.1f} MB algorithmic = {ab / avg / 1e3:.1f} GB/s = "
+                f"**{ab / avg / 1e3 / 8000.0:.4f} of 8 TB/s** (one launch per step holds the groups and tiles of all {len(step_kernel_row['matrices'])} matrices; "
+                "the tail launch follows it).", ""]
 
 # Per-kernel roofline fraction from the SINGLE-STREAM trace (HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0: the launches of a
 # step run one after the other, so a kernel's duration is its own): algorithmic bytes of the matrices in the grid
@@ -95,7 +122,7 @@ if single:
     (dst / f"{tag}_per_kernel_roofline.json").write_text(json.dumps({"method": "single-stream kernel trace (HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0), last 30 launches of every kernel; "
                                                                       "algorithmic bytes per grid from bench.py launch_classes (8*nnz+16*rows+4 per matrix); peak 8 TB/s",
                                                                       "kernels": table, "step_us_sum_of_kernels": round(sum(t["avg_us"] for t in table), 1)}, indent=1) + "\n")
-    out += ["## Per kernel, one stream (`HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0`, last 30 steps)", "",
+    out += ["## Per kernel, one stream (`HISPMV_BATCH_STREAMS=1 HISPMV_BATCH_GRAPH=0`: the grids of the classes one after the other, not the step kernel; last 30 steps)", "",
             "| kernel | workgroup | avg us | algorithmic MB per launch | GB/s | frac of 8 TB/s | matrices |", "|---|---:|---:|---:|---:|---:|---|"]
     for t in table:
         ab = t["algorithmic_bytes_per_launch"]
