@@ -276,7 +276,9 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
                     }
                 }
             }
-            if (slice_table.size() < (1u << 20) && tts_table.size() < (1u << 20) && q[0].size() + q[1].size() > 0) {
+            // (a call of tile streams alone keeps its grid: two power-law matrices cut into ~300 tiles of 35 - 110 us each leave the queue
+            // nothing short to end with -- 0.179 against 0.165 ms, profiles/r4_experiments/step_kernel/powerlaw.json)
+            if (slice_table.size() < (1u << 20) && tts_table.size() < (1u << 20) && !q[0].empty()) {
                 std::vector<QItem> order;
                 const int W = std::max(1, c->n_cus);
                 if (c->step_order == 2) {            // the order of the grids: tiles, 1024-thread groups, 256-thread groups (as the launches were)

@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--uniform", action="store_true", help="the pessimistic stand-in family")
     ap.add_argument("--matrices", default="")
+    ap.add_argument("--powerlaw", action="store_true", help="bench.py's powerlaw workload (R-MAT scale 20 + Zipf at soc-Pokec's shape) instead of the set")
     ap.add_argument("--out", default="gpurun_out/wg_timeline.json")
     ap.add_argument("--warm", type=int, default=200)
     ap.add_argument("--steps", type=int, default=3, help="traced steps (the LAST one is analysed, all are summarised)")
@@ -45,7 +46,7 @@ def main():
 
     names = [n for n in args.matrices.split(",") if n]
     r = bench.Runner(0, 1)
-    mats = bench.load_set(names, 0, 1, args.uniform)
+    mats = bench.load_powerlaw() if args.powerlaw else bench.load_set(names, 0, 1, args.uniform)
     r.add(mats)
     step = r.batch_step(mats)
     for _ in range(args.warm):
