@@ -29,8 +29,24 @@ void free_batch_plans(hispmv_ctx* c) {
 // workgroup size share a grid (largest first, so that the small ones fill the tail), ONE fix-up launch finishes the cut
 // rows of all parts (each on its own output: y for tile 0, the handle's partial vector for tile t > 0), ONE merge launch
 // adds the partial vectors of the column-tiled matrices to their y.
+static int build_batch_plan_with(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t n, const int32_t* idx, const float* const* d_x,
+                                 const float* const* bias, float* const* d_y, float beta, bool long_groups, bool& used_long_groups, bool& step_taken);
+// The batch layouts (groups up to four times as long, hispmv_choose.h) pay under the step kernel and cost under the grids on two lanes
+// (the set 0.289 -> 0.302 ms): a call that turns out not to qualify for the step kernel is planned again from the parts' first layouts.
 static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t n, const int32_t* idx, const float* const* d_x,
                             const float* const* bias, float* const* d_y, float beta) {
+    bool used = false, step = false;
+    int rc = build_batch_plan_with(c, plan, n, idx, d_x, bias, d_y, beta, true, used, step);
+    if (rc == HISPMV_OK && used && !step) {
+        for (auto& l : plan.launches) { dev_free(l.d_table); dev_free(l.d_table2); dev_free(l.d_items); dev_free(l.d_sync); }
+        plan.launches.clear();
+        rc = build_batch_plan_with(c, plan, n, idx, d_x, bias, d_y, beta, false, used, step);
+    }
+    return rc;
+}
+static int build_batch_plan_with(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t n, const int32_t* idx, const float* const* d_x,
+                                 const float* const* bias, float* const* d_y, float beta, bool long_groups, bool& used_long_groups, bool& step_taken) {
+    used_long_groups = false; step_taken = false;
     struct Ref { int i; size_t t; };
     struct Item { std::vector<Ref> refs; int threads; int64_t slices; bool strays = false; };      // strays: a part with stray slots (a grid class of its own)
     std::vector<Item> items;
@@ -40,7 +56,8 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
     const bool shared_chip = c->batch_streams > 1 && plan.stream_bytes >= c->batch_streams_min_bytes && !std::getenv("HISPMV_NO_BATCH_LAYOUT");
     auto dev_of = [&](const Ref& r) -> SpmvDeviceMatrix& {
         Matrix::Part& p = c->mats[idx[r.i]]->parts[r.t];
-        return (shared_chip && p.has_batch_dev) ? p.batch_dev : p.dev;
+        if (shared_chip && long_groups && p.has_batch_dev) { used_long_groups = true; return p.batch_dev; }
+        return p.dev;
     };
     auto out_of = [&](const Ref& r) -> float* {
         Matrix& m = *c->mats[idx[r.i]];
@@ -340,9 +357,11 @@ static int build_batch_plan(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int32_t 
                 HIP_TRY(c, hipMemcpy(S.d_items, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                 HIP_TRY(c, hipMalloc((void**)&S.d_sync, 2 * sizeof(unsigned)));
                 HIP_TRY(c, hipMemset(S.d_sync, 0, 2 * sizeof(unsigned)));
+                step_taken = true;
             }
         }
     }
+    if (long_groups && used_long_groups && !step_taken) return HISPMV_OK;        // (planned again from the first layouts: build_batch_plan)
     std::vector<Ref> fixrefs = refs;                            // + tile streams that cut long rows into pieces
     for (int i = 0; i < n; ++i) {
         const Matrix& m = *c->mats[idx[i]];

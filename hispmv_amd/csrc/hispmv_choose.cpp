@@ -21,6 +21,8 @@ FormatOptions FormatOptions::from_env() {
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
     o.no_stream_skip = std::getenv("HISPMV_NO_STREAM_SKIP") != nullptr;
     if (const char* e = std::getenv("HISPMV_BATCH_LAYOUT")) o.batch_layout = std::atoi(e) != 0;
+    if (const char* e = std::getenv("HISPMV_BATCH_GROUP_DIV")) o.batch_group_div = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("HISPMV_BATCH_GROUP_BELOW")) o.batch_group_below = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("HISPMV_LAYOUT")) o.device_layout = !std::strcmp(e, "device");
     if (const char* e = std::getenv("HISPMV_TTS_MAX_LINES")) o.tts_max_lines = std::atof(e);
     if (const char* e = std::getenv("HISPMV_TTS_TALL_SHAPE")) std::sscanf(e, "%d,%d,%d,%d,%d", &o.tall_rows, &o.tall_slots, &o.tall_tiles, &o.tall_zero_fill, &o.tall_parts);
@@ -116,12 +118,19 @@ void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p
 // The batch layout of a whole-matrix slice stream (HostPart::has_batch_layout): planned for half the CUs, kept when it is the same
 // kind of plan with longer groups.  Call BEFORE pack_part (which may release the words).
 void add_batch_layout(HostPart& p, int n_cus, const FormatOptions& opt) {
-    if (!opt.batch_layout || opt.decide_only || n_cus < 2 || p.plan.lds_floats <= 0 || p.plan.group_slices >= kBatchGroupBelow || p.st.n_slices < 512) return;
+    if (!opt.batch_layout || opt.decide_only || n_cus < 2 || p.plan.lds_floats <= 0 || p.plan.group_slices >= opt.batch_group_below || p.st.n_slices < 512) return;
     if (p.plan.group_slices != (p.st.n_slices + (int64_t)n_cus * p.plan.per_cu - 1) / ((int64_t)n_cus * p.plan.per_cu)) return;      // (resident plans only)
     SliceStream alt = p.st;                       // (headers, fix list, sizes; the words: columns again)
     alt.words = unplanned_words(p.st, p.plan);
-    LaunchPlan q = make_plan(alt, n_cus / 2);
-    if (q.block_threads != p.plan.block_threads || q.group_slices <= p.plan.group_slices || q.lds_floats <= 0 || q.ytile_floats != p.plan.ytile_floats) return;
+    // groups four times as long where such a plan is the same kind of plan (its windows still fit), else three times, else twice
+    LaunchPlan q;
+    bool found = false;
+    for (int div = opt.batch_group_div; div >= 2 && !found; --div) {
+        q = make_plan(alt, std::max(1, n_cus / div));
+        found = q.block_threads == p.plan.block_threads && q.group_slices > p.plan.group_slices && q.lds_floats > 0 && q.ytile_floats == p.plan.ytile_floats;
+        if (!found) alt.words = unplanned_words(p.st, p.plan);      // (make_plan rewrote the column fields of the words it staged)
+    }
+    if (!found) return;
     p.batch_dstream = pack_device_stream(alt, q, !opt.device_layout);
     if (opt.device_layout) p.batch_words = std::move(alt.words);
     p.batch_plan = std::move(q);

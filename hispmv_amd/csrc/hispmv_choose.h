@@ -23,8 +23,11 @@ struct HostPart {
     DeviceStream dstream;                        // the planned stream in its device layout (compact / wide groups)
     bool is_tts = false;
     TtsStream tts;
-    // BATCH LAYOUT (round 4): a second plan and device layout of the same slices with groups twice as long, for batch calls that
-    // share the chip between many matrices.  A resident plan gives a matrix one workgroup per CU; when its groups come out short
+    // BATCH LAYOUT (round 4): a second plan and device layout of the same slices with longer groups (four times, else three times,
+    // else twice as long: batch_group_div), for batch calls that share the chip between many matrices.  Since the step kernel an item of
+    // the queue pays 3 - 4 us of start-up (descriptor chain, first slice from HBM, window staging) whatever its length: resident groups
+    // below 80 slices (TSOPF, Si41Ge41H72, crankseg_2, nd6k, thread) take it: the set 0.2749 -> 0.2617 ms, the pessimistic family 0.2772 ->
+    // 0.2678 (profiles/r4_experiments/step_kernel/group_len.json).  First built for the two-lane grids:  A resident plan gives a matrix one workgroup per CU; when its groups come out short
     // (< kBatchGroupBelow slices: nd6k 27, thread 17) a workgroup spends a large part of its life staging its x window, which nothing
     // hides with one 1024-thread workgroup per CU.  Half as many workgroups of twice the length take 1.2 % off the step of the
     // benchmark set -- and 20 - 36 % longer when such a matrix runs alone on half the chip, which is why the single launches keep
@@ -34,7 +37,7 @@ struct HostPart {
     DeviceStream batch_dstream;
     WordVec batch_words;                         // (device_layout only: the planned host words of the batch layout)
 };
-constexpr int kBatchGroupBelow = 40;
+constexpr int kBatchGroupBelow = 80;
 
 struct FormatOptions {
     int format_mode = 2;          // HISPMV_FORMAT: 0 slices always, 1 tile stream whenever the plan has no window, 2 auto
@@ -53,6 +56,8 @@ struct FormatOptions {
                                   //   device (layout_on_device, byte-identical).  Off by default: the upload of the larger words from pageable
                                   //   memory costs more than the host packer saves (set of 20: prep + upload 1.38 s against 1.22 s)
     bool batch_layout = true;     // HISPMV_BATCH_LAYOUT=0: no second (long-group) layout for batch calls
+    int batch_group_div = 4;      // HISPMV_BATCH_GROUP_DIV: the batch layout is planned for n_cus / this many workgroups (then / 3, / 2 when that plan does not keep its kind)
+    int batch_group_below = kBatchGroupBelow;     // HISPMV_BATCH_GROUP_BELOW (experiments): resident groups shorter than this get the batch layout
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
     static FormatOptions from_env();
 };

@@ -1709,6 +1709,10 @@ __global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
         const unsigned it = s_next;
         if (it >= a.n_items) break;
         __syncthreads();                    // every thread has read the ticket: its slot may take the next one
+        // the NEXT item's ticket is drawn first thing: its round trip runs under the loads of this item's descriptor and table entry
+        // (a tile parks it in the LDS before its body starts -- no register to hold it across -- and by then most of the wait is over)
+        unsigned next = 0;
+        if (threadIdx.x == 0) next = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int2 item = load_const(a.items + __builtin_amdgcn_readfirstlane((int)it));
         const unsigned kind = (unsigned)__builtin_amdgcn_readfirstlane(item.x) & 3u;
         const int entry = (int)((unsigned)__builtin_amdgcn_readfirstlane(item.x) >> 8);
@@ -1722,9 +1726,8 @@ __global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
         WGT_BEGIN();
 #ifndef STEP_NO_TTS
         if (kind == 2) {
-            // a tile: the next ticket is drawn and parked in the LDS BEFORE the tile starts (no register to hold it across the
-            // body); thread 0's wavefront issues its first requests a memory round trip late, the other fifteen do not
-            if (tid == 0) s_next = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a tile: the next ticket is parked in the LDS BEFORE the tile starts (no register to hold it across the body)
+            if (tid == 0) s_next = next;
             // (experiment, StepArgs::stagger > 0: tiles that start in the same instant march through their streams in lockstep;
             // a delay of 0 .. stagger-1 quanta of ~0.2 us by tile index takes them out of step)
             for (int q = (int)((unsigned)index * 37u % (unsigned)(a.stagger > 0 ? a.stagger : 1)); q > 0; --q) __builtin_amdgcn_s_sleep(8);
@@ -1737,9 +1740,7 @@ __global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
 #endif
 #ifndef STEP_NO_SLICES
         {
-            // slice groups (91 - 97 VGPRs): the next ticket is in flight while the item runs and is consumed behind it
-            unsigned next = 0;
-            if (tid == 0) next = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // slice groups (91 - 97 VGPRs): the next ticket stays in flight while the item runs and is consumed behind it
             const MultiEntry t = load_const(a.slice_table + entry);
             const LookbackArgs lb{};
             // kind 0: the workgroup is the group's; kind 1: four groups of a 256-thread plan, wavefronts 4q .. 4q+3 take group index + q

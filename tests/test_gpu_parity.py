@@ -777,7 +777,7 @@ def test_host_vector_path_direct_and_copied_y(pyhispmv_mod, mode, monkeypatch):
 
 def test_batch_layout_of_short_groups(pyhispmv_mod, monkeypatch):
     """A resident plan whose groups come out short (here 6.9 M entries: 27 slices per workgroup, nd6k's case) gets a second device
-    layout with groups twice as long (hispmv_matrix_info.batch_group_slices) that hispmv_spmv_device_batch takes when the call
+    layout with groups two to four times as long (hispmv_matrix_info.batch_group_slices) that hispmv_spmv_device_batch takes when the call
     shares the chip (two lanes: >= 256 MiB of streams -- forced here with HISPMV_BATCH_STREAMS=2); single launches keep the first
     plan.  Same slices, same carries: the batch call's y equals the single launch's y bit for bit, with the layout on and off, next
     to a large matrix and a tile stream in the same call."""
@@ -790,7 +790,7 @@ def test_batch_layout_of_short_groups(pyhispmv_mod, monkeypatch):
     c = np.clip(r + rng.integers(-2500, 2501, r.size), 0, cols - 1).astype(np.int32)
     r = r.astype(np.int32)
     v = rng.random(r.size, dtype=np.float32) - np.float32(0.5)
-    rows2 = cols2 = 60000                                         # a second, larger slice matrix (groups of > 40 slices: no batch layout)
+    rows2 = cols2 = 100000                                        # a second, larger slice matrix (groups of > 80 slices: no batch layout)
     r2 = np.repeat(np.arange(rows2, dtype=np.int64), 300)
     c2 = np.clip(r2 + rng.integers(-1500, 1501, r2.size), 0, cols2 - 1).astype(np.int32)
     r2 = r2.astype(np.int32)
@@ -807,9 +807,11 @@ def test_batch_layout_of_short_groups(pyhispmv_mod, monkeypatch):
         h.load_matrices()
         info1, info2 = h.matrix_info(i1), h.matrix_info(i2)
         assert info1["block_threads"] == 1024 and info1["group_slices"] < 40 and info1["lds_bytes"] > 0, info1
-        assert info1["batch_group_slices"] == (2 * info1["group_slices"] if layout == "1" else 0) or \
-               (layout == "1" and abs(info1["batch_group_slices"] - 2 * info1["group_slices"]) <= 2), info1
-        assert info2["batch_group_slices"] == 0 and info2["group_slices"] >= 40, info2
+        if layout == "1":       # four times as long where that plan keeps its kind, else three times, else twice
+            assert any(abs(info1["batch_group_slices"] - k * info1["group_slices"]) <= k for k in (2, 3, 4)), info1
+        else:
+            assert info1["batch_group_slices"] == 0, info1
+        assert info2["batch_group_slices"] == 0 and info2["group_slices"] >= 80, info2
         dx, db, dx2, db2 = (torch.from_numpy(a).to(dev) for a in (x, b, x2, b2))
         dy = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev)
         dy2 = torch.full((rows2,), float("nan"), dtype=torch.float32, device=dev)
