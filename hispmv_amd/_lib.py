@@ -83,6 +83,7 @@ SIGNATURES = {
     "hispmv_prep_dims": (C.c_int, [_p, _i64p]),
     "hispmv_prep_plan": (C.c_int, [_p, C.c_int, _i64p]),
     "hispmv_prep_choose_format": (C.c_int, [_p, C.c_int, _i64p]),
+    "hispmv_prep_step_queue": (C.c_int, [_p, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, _p, _p]),
     "hispmv_prep_window_membership": (C.c_int, [_p, C.c_int, C.c_void_p]),
     "hispmv_prep_apply_plan": (C.c_int, [_p, C.c_int, _i64p]),
     "hispmv_prep_groups": (_i32p, [_p]),

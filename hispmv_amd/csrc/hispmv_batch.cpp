@@ -296,35 +296,12 @@ static int build_batch_plan_with(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int
             // (a call of tile streams alone keeps its grid: two power-law matrices cut into ~300 tiles of 35 - 110 us each leave the queue
             // nothing short to end with -- 0.179 against 0.165 ms, profiles/r4_experiments/step_kernel/powerlaw.json)
             if (slice_table.size() < (1u << 20) && tts_table.size() < (1u << 20) && !q[0].empty()) {
-                std::vector<QItem> order;
                 const int W = std::max(1, c->n_cus);
-                if (c->step_order == 2) {            // the order of the grids: tiles, 1024-thread groups, 256-thread groups (as the launches were)
-                    for (const QItem& it : q[1]) order.push_back(it);
-                    for (const QItem& it : q[0]) order.push_back(it);
-                } else {
-                    for (auto& v : q) std::stable_sort(v.begin(), v.end(), [](const QItem& x, const QItem& y) { return x.cost > y.cost; });
-                    double total[2] = {0, 0}, done[2] = {0, 0};
-                    for (int k = 0; k < 2; ++k) for (const QItem& it : q[k]) total[k] += it.cost;
-                    const double T = (total[0] + total[1]) / W;      // the step if nothing idles
-                    size_t pos[2] = {0, 0};
-                    while (pos[0] < q[0].size() || pos[1] < q[1].size()) {
-                        int k;
-                        if (pos[0] >= q[0].size()) k = 1;
-                        else if (pos[1] >= q[1].size()) k = 0;
-                        else if (c->step_order == 1) k = q[1][pos[1]].cost > q[0][pos[0]].cost ? 1 : 0;       // longest first
-                        else {
-                            // the LONG tiles (more than a quarter of the step: soc-Pokec's) alternate with the longest slice groups, so that
-                            // the cache-bound tiles and the HBM-bound groups start side by side on different CUs and every long tile has
-                            // started within the first third of the step; behind them: longest first
-                            const bool long_tile = q[1][pos[1]].cost > 0.25 * T;
-                            if (long_tile) k = (pos[0] + pos[1]) % 2 == 0 ? 1 : 0;
-                            else k = q[1][pos[1]].cost > q[0][pos[0]].cost ? 1 : 0;
-                        }
-                        order.push_back(q[k][pos[k]]);
-                        done[k] += q[k][pos[k]].cost;
-                        ++pos[k];
-                    }
-                }
+                // the order of the queue: host-only code (hispmv_choose.cpp: order_step_queue; tests/test_step_queue.py)
+                std::vector<double> cost[2];
+                for (int k = 0; k < 2; ++k) for (const QItem& it : q[k]) cost[k].push_back(it.cost);
+                std::vector<QItem> order;
+                for (const auto& pr : order_step_queue(cost[0], cost[1], W, c->step_order)) order.push_back(q[pr.first][(size_t)pr.second]);
                 std::vector<uint32_t> packed;
                 packed.reserve(order.size() * 2);
                 for (const QItem& it : order) { packed.push_back(it.a); packed.push_back(it.b); }

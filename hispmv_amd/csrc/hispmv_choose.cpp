@@ -501,4 +501,37 @@ FormatChoice choose_format(Csr&& csr, SliceStream* prebuilt, int n_cus, const Fo
     return out;
 }
 
+std::vector<std::pair<int, int>> order_step_queue(const std::vector<double>& slice_costs, const std::vector<double>& tile_costs, int n_wg, int mode) {
+    const std::vector<double>* cost[2] = {&slice_costs, &tile_costs};
+    std::vector<std::pair<int, int>> out;
+    out.reserve(slice_costs.size() + tile_costs.size());
+    if (mode == 2) {
+        for (size_t i = 0; i < tile_costs.size(); ++i) out.emplace_back(1, (int)i);
+        for (size_t i = 0; i < slice_costs.size(); ++i) out.emplace_back(0, (int)i);
+        return out;
+    }
+    std::vector<int> idx[2];
+    double total = 0;
+    for (int k = 0; k < 2; ++k) {
+        idx[k].resize(cost[k]->size());
+        for (size_t i = 0; i < idx[k].size(); ++i) { idx[k][i] = (int)i; total += (*cost[k])[i]; }
+        std::stable_sort(idx[k].begin(), idx[k].end(), [&](int a, int b) { return (*cost[k])[(size_t)a] > (*cost[k])[(size_t)b]; });
+    }
+    const double T = total / std::max(1, n_wg);          // the step if nothing idles
+    size_t pos[2] = {0, 0};
+    while (pos[0] < idx[0].size() || pos[1] < idx[1].size()) {
+        int k;
+        if (pos[0] >= idx[0].size()) k = 1;
+        else if (pos[1] >= idx[1].size()) k = 0;
+        else {
+            const double c0 = (*cost[0])[(size_t)idx[0][pos[0]]], c1 = (*cost[1])[(size_t)idx[1][pos[1]]];
+            if (mode == 0 && c1 > 0.25 * T) k = (pos[0] + pos[1]) % 2 == 0 ? 1 : 0;      // long tiles alternate with the longest slice items
+            else k = c1 > c0 ? 1 : 0;                                                     // longest first
+        }
+        out.emplace_back(k, idx[k][pos[k]]);
+        ++pos[k];
+    }
+    return out;
+}
+
 }  // namespace hispmv

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <utility>
 #include <vector>
 
 #include "hispmv_plan.h"
@@ -61,6 +62,14 @@ struct FormatOptions {
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)
     static FormatOptions from_env();
 };
+
+// The queue of the step kernel (hispmv_kernels.h: launch_spmv_step), host-only: items of two classes -- slice items (a 1024-thread group
+// or four 256-thread groups) and tiles -- with a cost each in microseconds of a CU, `n_wg` workgroups drawing them in queue order.
+//   mode 0 (default): the LONG tiles (cost > a quarter of the step, total cost / n_wg) alternate with the longest slice items, so that
+//          cache-bound tiles and HBM-bound groups start side by side and every long tile has started early; behind them longest first;
+//   mode 1: longest first (both classes merged by cost);  mode 2: all tiles, then all slice items, each in the order given.
+// -> for every queue position {class (0 slice item, 1 tile), index into that class's list}.
+std::vector<std::pair<int, int>> order_step_queue(const std::vector<double>& slice_costs, const std::vector<double>& tile_costs, int n_wg, int mode);
 
 struct FormatChoice {
     int format = 0;               // 0 slice stream(s), 1 transposed tile stream(s)

@@ -94,6 +94,18 @@ HISPMV_API int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_
     } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
 }
 
+HISPMV_API int hispmv_prep_step_queue(const double* slice_costs, int32_t n_slice, const double* tile_costs, int32_t n_tile, int32_t n_wg, int32_t mode,
+                                      int32_t* out_class, int32_t* out_index) {
+    if (n_slice < 0 || n_tile < 0 || n_wg <= 0 || mode < 0 || mode > 2 || (n_slice > 0 && !slice_costs) || (n_tile > 0 && !tile_costs) ||
+        (n_slice + n_tile > 0 && (!out_class || !out_index))) return HISPMV_EINVAL;
+    try {
+        const std::vector<double> a(slice_costs, slice_costs + n_slice), b(tile_costs, tile_costs + n_tile);
+        const auto order = order_step_queue(a, b, n_wg, mode);
+        for (size_t i = 0; i < order.size(); ++i) { out_class[i] = order[i].first; out_index[i] = order[i].second; }
+        return HISPMV_OK;
+    } catch (const std::exception& ex) { g_prep_err = ex.what(); return HISPMV_EINVAL; }
+}
+
 // inside[nnz]: 1 for the CSR entries whose block of x lies in the window of their workgroup under the launch plan for n_cus CUs
 // (the criterion of the stray split, hispmv_matrix_info.tile_kind 3).  For tests: lets the wavefront model pack the two parts.
 HISPMV_API int hispmv_prep_window_membership(const hispmv_prep* p, int n_cus, uint8_t* inside) {

@@ -218,3 +218,18 @@ def device_layout_from_coo(coo_rows, coo_cols, coo_values, rows: int, cols: int,
                     stray_cols=arr(2, n_slices * 64 if stray_floats else 0, np.uint32).reshape(-1, 64))
     finally:
         lib.hispmv_prep_free(p)
+
+
+def step_queue(slice_costs, tile_costs, n_wg: int = 256, mode: int = 0):
+    """The order of the step kernel's queue (hispmv_prep_step_queue: the function the batch planner calls), host-only.
+    -> (classes, indices): per queue position 0 = slice item / 1 = tile, and its index in that class's cost list."""
+    a = np.ascontiguousarray(slice_costs, dtype=np.float64)
+    b = np.ascontiguousarray(tile_costs, dtype=np.float64)
+    n = a.size + b.size
+    cls = np.zeros(n, np.int32)
+    idx = np.zeros(n, np.int32)
+    rc = lib.hispmv_prep_step_queue(C.c_void_p(a.ctypes.data) if a.size else None, a.size, C.c_void_p(b.ctypes.data) if b.size else None, b.size,
+                                    int(n_wg), int(mode), C.c_void_p(cls.ctypes.data) if n else None, C.c_void_p(idx.ctypes.data) if n else None)
+    if rc != HISPMV_OK:
+        raise ValueError("hispmv_prep_step_queue: invalid argument")
+    return cls, idx

@@ -227,6 +227,14 @@ int hispmv_prep_plan(const hispmv_prep* p, int n_cus, int64_t plan[6]);
  * _TTS_MIN_NNZ switches like the loader. */
 int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_t out[16]);
 
+/* The order of the step kernel's queue (hispmv_spmv_device_batch, hispmv_batch_call_info), host-only (hispmv_choose.cpp:
+ * order_step_queue, the function the batch planner calls): n_slice slice items and n_tile tiles with a cost each (microseconds of a
+ * CU), n_wg workgroups; mode 0 = long tiles (> a quarter of the step) alternating with the longest slice items, then longest first
+ * (default), 1 = longest first, 2 = tiles then slice items as given.  out_class[i] (0 slice item, 1 tile) and out_index[i] name the
+ * item at queue position i (n_slice + n_tile positions).  No reference counterpart (the reference runs one matrix at a time). */
+int hispmv_prep_step_queue(const double* slice_costs, int32_t n_slice, const double* tile_costs, int32_t n_tile, int32_t n_wg, int32_t mode,
+                           int32_t* out_class, int32_t* out_index);
+
 /* inside[nnz] (CSR order): 1 for the entries whose 64-byte block of x is held by the x window of their workgroup under the launch
  * plan for n_cus compute units, 0 for the entries that gather through L2 -- the criterion by which the loader splits a matrix with a
  * few per cent of stray couplings into a windowed part and a stray part (hispmv_matrix_info.tile_kind 3). */

@@ -103,5 +103,23 @@ int main(int argc, char** argv) {
         }
         std::printf("stencil: slices %lld, %d threads, %d slices per workgroup, window %d floats\n", (long long)st.n_slices, p.block_threads, p.group_slices, p.lds_floats);
     }
+    {   // the order of the step kernel's queue (order_step_queue): all three modes, empty classes, every item exactly once
+        std::vector<double> sl, tl;
+        for (int i = 0; i < 700; ++i) sl.push_back(10.0 + (i * 37 % 41));
+        for (int i = 0; i < 300; ++i) tl.push_back(i < 120 ? 100.0 + i % 7 : 15.0 + i % 13);
+        for (int mode = 0; mode < 3; ++mode) {
+            for (int empty = 0; empty < 3; ++empty) {
+                const std::vector<double> a = empty == 1 ? std::vector<double>() : sl, b = empty == 2 ? std::vector<double>() : tl;
+                const auto order = order_step_queue(a, b, 64, mode);
+                std::vector<int> seen_a(a.size(), 0), seen_b(b.size(), 0);
+                for (const auto& pr : order) (pr.first ? seen_b : seen_a)[(size_t)pr.second]++;
+                bool ok = order.size() == a.size() + b.size();
+                for (int q : seen_a) ok = ok && q == 1;
+                for (int q : seen_b) ok = ok && q == 1;
+                if (!ok) { std::puts("order_step_queue: an item is missing or doubled"); return 1; }
+            }
+        }
+        std::puts("step queue: 3 modes x 3 class mixes, every item once");
+    }
     std::puts("sanitize_host: done");
 }

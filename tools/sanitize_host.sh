@@ -1,6 +1,6 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the host side of the library (reader, COO->CSR, slice stream, launch planner, device
-# layout, transposed tile stream, format / tiling choice).
+# layout, transposed tile stream, format / tiling choice, the order of the step kernel's queue).
 # GPU sanitizers are not available on the test pool; the device side is covered by the bit-exact parity tests.
 set -e
 cd "$(dirname "$0")/.."
