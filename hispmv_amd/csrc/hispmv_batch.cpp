@@ -284,7 +284,8 @@ static int build_batch_plan_with(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int
                         // 0.85 us per 1024-element slice with 23 lines of x per gather (soc-Pokec), scaled by the line model of DESIGN.md 2.2
                         double lines = 23.0;
                         for (int i = 0; i < n; ++i) { const Matrix& m = *c->mats[idx[i]]; if (!m.dense && m.format == 1 && m.parts[0].tdev.words == te.m.words && m.tts_lines_per_gather > 0) lines = m.tts_lines_per_gather; }
-                        const double per_slice = 0.85 * (50.0 + 2.8 * lines) / (50.0 + 2.8 * 23.0);
+                        static const double tile_scale = std::getenv("HISPMV_STEP_TILE_SCALE") ? std::atof(std::getenv("HISPMV_STEP_TILE_SCALE")) : 1.0;
+                        const double per_slice = tile_scale * 0.85 * (50.0 + 2.8 * lines) / (50.0 + 2.8 * 23.0);
                         for (int t = 0; t < te.m.n_tiles; ++t) {
                             int64_t sl = 0;
                             for (int b = tiles[(size_t)t].z; b < tiles[(size_t)t].z + tiles[(size_t)t].w; ++b) sl += blocks[(size_t)b * 2].y;
