@@ -56,6 +56,14 @@ def _run(torch, mats, env, reps=1, beta=BETA):
         h.synchronize()
         torch.cuda.synchronize()
         info = [h.matrix_info(i) for i in idx]
+        # the library says how it issued the call (hispmv_batch_call_info): the step kernel exactly when the context asked for it
+        call = h.batch_call_info()
+        want_step = env.get("HISPMV_STEP_KERNEL", "1") != "0"
+        assert call["step_kernel"] == want_step, (env, call)
+        if want_step:
+            assert call["launches"] <= 2 and call["streams"] == 1 and call["items"] > 0, call        # ONE main launch (+ the tail) on the caller's stream
+        else:
+            assert call["items"] == 0 and call["launches"] >= 3, call                                  # a grid per class (+ the tail)
         return [t.cpu().numpy() for t in dy], info
     finally:
         h.close()
