@@ -22,6 +22,7 @@ FormatOptions FormatOptions::from_env() {
     o.no_stream_skip = std::getenv("HISPMV_NO_STREAM_SKIP") != nullptr;
     if (const char* e = std::getenv("HISPMV_BATCH_LAYOUT")) o.batch_layout = std::atoi(e) != 0;
     if (const char* e = std::getenv("HISPMV_BATCH_GROUP_DIV")) o.batch_group_div = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("HISPMV_BATCH_MIN_SLICES")) o.batch_min_slices = std::max<int64_t>(1, std::atoll(e));
     if (const char* e = std::getenv("HISPMV_BATCH_GROUP_BELOW")) o.batch_group_below = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("HISPMV_LAYOUT")) o.device_layout = !std::strcmp(e, "device");
     if (const char* e = std::getenv("HISPMV_TTS_MAX_LINES")) o.tts_max_lines = std::atof(e);
@@ -118,7 +119,7 @@ void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p
 // The batch layout of a whole-matrix slice stream (HostPart::has_batch_layout): planned for half the CUs, kept when it is the same
 // kind of plan with longer groups.  Call BEFORE pack_part (which may release the words).
 void add_batch_layout(HostPart& p, int n_cus, const FormatOptions& opt) {
-    if (!opt.batch_layout || opt.decide_only || n_cus < 2 || p.plan.lds_floats <= 0 || p.plan.group_slices >= opt.batch_group_below || p.st.n_slices < 512) return;
+    if (!opt.batch_layout || opt.decide_only || n_cus < 2 || p.plan.lds_floats <= 0 || p.plan.group_slices >= opt.batch_group_below || p.st.n_slices < opt.batch_min_slices) return;
     if (p.plan.group_slices != (p.st.n_slices + (int64_t)n_cus * p.plan.per_cu - 1) / ((int64_t)n_cus * p.plan.per_cu)) return;      // (resident plans only)
     SliceStream alt = p.st;                       // (headers, fix list, sizes; the words: columns again)
     alt.words = unplanned_words(p.st, p.plan);
