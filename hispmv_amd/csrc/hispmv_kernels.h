@@ -170,7 +170,7 @@ hipError_t launch_tts_multi(const TtsEntry* entries, int n, const uint8_t* item_
 // kind 0 = group `index` of slice_table[entry] (a 1024-thread plan), 1 = groups index .. index + 3 of a 256-thread plan, 2 = tile
 // `index` of tts_table[entry] (standard geometry, x gathered through the cache).  d_sync: two zeroed words the kernel rearms itself.
 // `strays`: some slice part has stray slots.
-struct StepArgs { const MultiEntry* slice_table; const TtsEntry* tts_table; const int2* items; unsigned* sync; unsigned n_items; float alpha; int stagger, ticket_word; };
+struct StepArgs { const MultiEntry* slice_table; const TtsEntry* tts_table; const int2* items; unsigned* sync; unsigned n_items; float alpha; int pad, ticket_word; };
 hipError_t launch_spmv_step(const MultiEntry* d_slice_table, const TtsEntry* d_tts_table, const void* d_items, unsigned n_items,
                             unsigned* d_sync, int workgroups, size_t lds_bytes, bool strays, float alpha, hipStream_t stream);
 size_t tts_tile_lds_bytes(const TtsDeviceMatrix& m);

@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
         typedef const __attribute__((address_space(4))) StepArgs* KernArgs;
         KernArgs ap = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ap));
-        const StepArgs a{ap->slice_table, ap->tts_table, ap->items, ap->sync, ap->n_items, ap->alpha, ap->stagger, ap->ticket_word};
+        const StepArgs a{ap->slice_table, ap->tts_table, ap->items, ap->sync, ap->n_items, ap->alpha, 0, ap->ticket_word};
         unsigned& s_next = *(unsigned*)(step_lds + a.ticket_word);
         const unsigned it = s_next;
         if (it >= a.n_items) break;
@@ -1724,22 +1724,15 @@ __global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
         asm volatile("" : "+v"(tid));
         const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
         WGT_BEGIN();
-#ifndef STEP_NO_TTS
         if (kind == 2) {
             // a tile: the next ticket is parked in the LDS BEFORE the tile starts (no register to hold it across the body)
             if (tid == 0) s_next = next;
-            // (experiment, StepArgs::stagger > 0: tiles that start in the same instant march through their streams in lockstep;
-            // a delay of 0 .. stagger-1 quanta of ~0.2 us by tile index takes them out of step)
-            for (int q = (int)((unsigned)index * 37u % (unsigned)(a.stagger > 0 ? a.stagger : 1)); q > 0; --q) __builtin_amdgcn_s_sleep(8);
             // (the tables through the CONSTANT address space: scalar loads -- as generic pointers read from memory they became
             // flat loads into some forty VGPRs)
             const TtsEntry e = load_const(a.tts_table + entry);
             if (e.beta != 0.0f) tts_tile_body<true>(e.m, e.x, e.bias, e.y, a.alpha, e.beta, (int)index, tid);
             else tts_tile_body<false>(e.m, e.x, e.y, e.y, a.alpha, 0.0f, (int)index, tid);
-        } else
-#endif
-#ifndef STEP_NO_SLICES
-        {
+        } else {
             // slice groups (91 - 97 VGPRs): the next ticket stays in flight while the item runs and is consumed behind it
             const MultiEntry t = load_const(a.slice_table + entry);
             const LookbackArgs lb{};
@@ -1754,9 +1747,6 @@ __global__ __launch_bounds__(1024) void spmv_step_kernel(StepArgs args) {
                                                         t.n_slices, t.group_slices, t.lds_floats, t.ytile_floats, t.cols, t.rows, lb, group, sb);
             if (tid == 0) s_next = next;
         }
-#else
-        {}
-#endif
         // the item's LDS is free and the next ticket visible behind this barrier
 #ifdef HISPMV_WG_TRACE
         WGT_END(kind == 2 ? 3 : kind == 0 ? 1 : 2, entry, index);        // (contains the barrier)
@@ -1929,12 +1919,11 @@ hipError_t launch_spmv_step(const MultiEntry* d_slice_table, const TtsEntry* d_t
         if ((e = hipFuncSetAttribute((const void*)spmv_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
         raised = true;
     }
-    static const int stagger = std::getenv("HISPMV_STEP_STAGGER") ? std::atoi(std::getenv("HISPMV_STEP_STAGGER")) : 0;
     // (+ 16 bytes behind the items' LDS for the ticket word)
     const size_t ticket_byte = (lds_bytes + 15) & ~(size_t)15;
     lds_bytes = ticket_byte + 16;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    const StepArgs a{d_slice_table, d_tts_table, (const int2*)d_items, d_sync, n_items, alpha, stagger, (int)(ticket_byte / 4)};
+    const StepArgs a{d_slice_table, d_tts_table, (const int2*)d_items, d_sync, n_items, alpha, 0, (int)(ticket_byte / 4)};
     if (strays) hipLaunchKernelGGL(spmv_step_kernel<true>, dim3((unsigned)workgroups), dim3(1024), lds_bytes, stream, a);
     else hipLaunchKernelGGL(spmv_step_kernel<false>, dim3((unsigned)workgroups), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
