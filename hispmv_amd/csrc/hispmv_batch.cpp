@@ -210,7 +210,7 @@ static int build_batch_plan_with(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int
     // The step kernel: when the call shares the chip between its matrices and every main launch is a slice grid (1024- or 256-thread
     // plans, no XCD-pinned column tiles) or a tile-stream grid of the standard geometry, the main launches collapse into ONE launch
     // whose items -- a 1024-thread group, four 256-thread groups, a tile -- are drawn from a queue by one persistent workgroup per CU
-    // (hispmv_kernels.hip: spmv_step_kernel; per-CU occupancy before / after: profiles/r4_experiments/wg_timeline.json).
+    // (hispmv_kernels.hip: spmv_step_kernel; per-CU occupancy before / after: profiles/r4_experiments/step_kernel/).
     if (c->step_kernel && shared_chip && !c->cu_split && !c->batch_graphs) {
         bool ok = true;
         size_t lds = 0;
@@ -240,8 +240,6 @@ static int build_batch_plan_with(hispmv_ctx* c, hispmv_ctx::BatchPlan& plan, int
             std::vector<QItem> q[2];
             std::vector<MultiEntry> slice_table;
             std::vector<TtsEntry> tts_table;
-            double compact_frac_of[1] = {0};
-            (void)compact_frac_of;
             for (const auto& l : plan.launches) {
                 if (l.kind == 0) {
                     for (size_t e = 0; e < l.multi.size(); ++e) {
