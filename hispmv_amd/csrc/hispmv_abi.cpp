@@ -290,7 +290,7 @@ HISPMV_API int hispmv_create(hispmv_ctx** out, const char* xclbin_path, int devi
         c->carry_mode = !std::strcmp(env, "fixup") ? 0 : !std::strcmp(env, "lookback") ? 1 : !std::strcmp(env, "ticket") ? 3 : !std::strcmp(env, "resident") ? 5 : 2;
     if (const char* env = std::getenv("HISPMV_BATCH_GRAPH")) c->batch_graphs = std::atoi(env) != 0;
     if (const char* env = std::getenv("HISPMV_STEP_KERNEL")) c->step_kernel = std::atoi(env) != 0;
-    if (const char* env = std::getenv("HISPMV_STEP_ORDER")) c->step_order = !std::strcmp(env, "lpt") ? 1 : !std::strcmp(env, "grid") ? 2 : 0;
+    if (const char* env = std::getenv("HISPMV_STEP_ORDER")) c->step_order = !std::strcmp(env, "lpt") ? 1 : !std::strcmp(env, "grid") ? 2 : !std::strcmp(env, "alt2") ? 3 : !std::strcmp(env, "alt3") ? 4 : std::atoi(env) >= 16 ? std::atoi(env) : 0;
     if (const char* env = std::getenv("HISPMV_BATCH_ORDER")) c->batch_order = !std::strcmp(env, "small_first") ? 1 : 0;
     if (const char* env = std::getenv("HISPMV_BATCH_LANES")) c->batch_lanes_heavy_first = std::strcmp(env, "rr") != 0;
     if (const char* env = std::getenv("HISPMV_BATCH_STREAMS")) { c->batch_streams = std::max(1, std::min(3, std::atoi(env))); c->batch_streams_min_bytes = 0; }

@@ -526,7 +526,10 @@ std::vector<std::pair<int, int>> order_step_queue(const std::vector<double>& sli
         else if (pos[1] >= idx[1].size()) k = 0;
         else {
             const double c0 = (*cost[0])[(size_t)idx[0][pos[0]]], c1 = (*cost[1])[(size_t)idx[1][pos[1]]];
-            if (mode == 0 && c1 > 0.25 * T) k = (pos[0] + pos[1]) % 2 == 0 ? 1 : 0;      // long tiles alternate with the longest slice items
+            // long tiles alternate with the longest slice items (mode 0: one to one; modes 3, 4: two / three slice items per long tile)
+            // (mode >= 16, experiments: cycles of (mode >> 4) long tiles and (mode & 15) slice items)
+            const int nt = mode >= 16 ? std::max(1, mode >> 4) : 1, ns = mode >= 16 ? std::max(1, mode & 15) : mode == 3 ? 2 : mode == 4 ? 3 : 1;
+            if ((mode == 0 || mode == 3 || mode == 4 || mode >= 16) && c1 > 0.25 * T) k = (pos[0] + pos[1]) % (size_t)(nt + ns) < (size_t)nt ? 1 : 0;
             else k = c1 > c0 ? 1 : 0;                                                     // longest first
         }
         out.emplace_back(k, idx[k][pos[k]]);

@@ -68,7 +68,9 @@ struct FormatOptions {
 // or four 256-thread groups) and tiles -- with a cost each in microseconds of a CU, `n_wg` workgroups drawing them in queue order.
 //   mode 0 (default): the LONG tiles (cost > a quarter of the step, total cost / n_wg) alternate with the longest slice items, so that
 //          cache-bound tiles and HBM-bound groups start side by side and every long tile has started early; behind them longest first;
-//   mode 1: longest first (both classes merged by cost);  mode 2: all tiles, then all slice items, each in the order given.
+//   mode 1: longest first (both classes merged by cost);  mode 2: all tiles, then all slice items, each in the order given;
+//   modes 3, 4, 16*t + s (experiments): two / three slice items per long tile; cycles of t long tiles and s slice items -- all measured
+//   worse than one to one (profiles/r4_experiments/step_kernel/summary.json: head_of_the_queue).
 // -> for every queue position {class (0 slice item, 1 tile), index into that class's list}.
 std::vector<std::pair<int, int>> order_step_queue(const std::vector<double>& slice_costs, const std::vector<double>& tile_costs, int n_wg, int mode);
 

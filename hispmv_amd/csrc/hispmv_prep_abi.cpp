@@ -96,7 +96,7 @@ HISPMV_API int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_
 
 HISPMV_API int hispmv_prep_step_queue(const double* slice_costs, int32_t n_slice, const double* tile_costs, int32_t n_tile, int32_t n_wg, int32_t mode,
                                       int32_t* out_class, int32_t* out_index) {
-    if (n_slice < 0 || n_tile < 0 || n_wg <= 0 || mode < 0 || mode > 2 || (n_slice > 0 && !slice_costs) || (n_tile > 0 && !tile_costs) ||
+    if (n_slice < 0 || n_tile < 0 || n_wg <= 0 || mode < 0 || (mode > 4 && mode < 16) || mode > 255 || (n_slice > 0 && !slice_costs) || (n_tile > 0 && !tile_costs) ||
         (n_slice + n_tile > 0 && (!out_class || !out_index))) return HISPMV_EINVAL;
     try {
         const std::vector<double> a(slice_costs, slice_costs + n_slice), b(tile_costs, tile_costs + n_tile);

@@ -230,7 +230,8 @@ int hispmv_prep_choose_format(const hispmv_prep* p, int n_cus, int64_t out[16]);
 /* The order of the step kernel's queue (hispmv_spmv_device_batch, hispmv_batch_call_info), host-only (hispmv_choose.cpp:
  * order_step_queue, the function the batch planner calls): n_slice slice items and n_tile tiles with a cost each (microseconds of a
  * CU), n_wg workgroups; mode 0 = long tiles (> a quarter of the step) alternating with the longest slice items, then longest first
- * (default), 1 = longest first, 2 = tiles then slice items as given.  out_class[i] (0 slice item, 1 tile) and out_index[i] name the
+ * (default), 1 = longest first, 2 = tiles then slice items as given (3, 4, 16*t + s: experiments -- two / three slice items per long tile,
+ * cycles of t long tiles and s slice items).  out_class[i] (0 slice item, 1 tile) and out_index[i] name the
  * item at queue position i (n_slice + n_tile positions).  No reference counterpart (the reference runs one matrix at a time). */
 int hispmv_prep_step_queue(const double* slice_costs, int32_t n_slice, const double* tile_costs, int32_t n_tile, int32_t n_wg, int32_t mode,
                            int32_t* out_class, int32_t* out_index);

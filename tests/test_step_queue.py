@@ -76,4 +76,4 @@ def test_degenerate_calls():
     with pytest.raises(ValueError):
         prep.step_queue([1.0], [1.0], 0, 0)
     with pytest.raises(ValueError):
-        prep.step_queue([1.0], [1.0], 4, 3)
+        prep.step_queue([1.0], [1.0], 4, 5)
