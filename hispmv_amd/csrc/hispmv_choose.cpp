@@ -21,6 +21,7 @@ FormatOptions FormatOptions::from_env() {
     o.tts_small = std::getenv("HISPMV_TTS_SMALL") != nullptr;
     o.no_stream_skip = std::getenv("HISPMV_NO_STREAM_SKIP") != nullptr;
     if (const char* e = std::getenv("HISPMV_BATCH_LAYOUT")) o.batch_layout = std::atoi(e) != 0;
+    if (const char* e = std::getenv("HISPMV_BATCH_PLAN_SEARCH")) o.batch_plan_search = std::atoi(e) != 0;
     if (const char* e = std::getenv("HISPMV_BATCH_GROUP_DIV")) o.batch_group_div = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("HISPMV_BATCH_MIN_SLICES")) o.batch_min_slices = std::max<int64_t>(1, std::atoll(e));
     if (const char* e = std::getenv("HISPMV_BATCH_GROUP_BELOW")) o.batch_group_below = std::max(1, std::atoi(e));
@@ -121,13 +122,16 @@ void finish_part(HostPart& p, int n_cus, const FormatOptions& opt) { plan_part(p
 void add_batch_layout(HostPart& p, int n_cus, const FormatOptions& opt) {
     if (!opt.batch_layout || opt.decide_only || n_cus < 2 || p.plan.lds_floats <= 0 || p.plan.group_slices >= opt.batch_group_below || p.st.n_slices < opt.batch_min_slices) return;
     if (p.plan.group_slices != (p.st.n_slices + (int64_t)n_cus * p.plan.per_cu - 1) / ((int64_t)n_cus * p.plan.per_cu)) return;      // (resident plans only)
-    SliceStream alt = p.st;                       // (headers, fix list, sizes; the words: columns again)
-    alt.words = unplanned_words(p.st, p.plan);
+    WordVec keep = std::move(p.st.words);         // (the copy below takes the headers, the fix list and the sizes, not 8 bytes per element)
+    SliceStream alt = p.st;
+    p.st.words = std::move(keep);
+    alt.words = unplanned_words(p.st, p.plan);    // the words with their columns again
     // groups four times as long where such a plan is the same kind of plan (its windows still fit), else three times, else twice
     LaunchPlan q;
     bool found = false;
     for (int div = opt.batch_group_div; div >= 2 && !found; --div) {
-        q = make_plan(alt, std::max(1, n_cus / div));
+        // (only the resident configuration of the first plan: the other five cannot be "the same kind of plan with longer groups")
+        q = make_plan(alt, std::max(1, n_cus / div), opt.batch_plan_search ? -1 : p.plan.block_threads == 1024 ? kPlanCfgResident1024 : p.plan.block_threads == 512 ? kPlanCfgResident512 : -1);
         found = q.block_threads == p.plan.block_threads && q.group_slices > p.plan.group_slices && q.lds_floats > 0 && q.ytile_floats == p.plan.ytile_floats;
         if (!found) alt.words = unplanned_words(p.st, p.plan);      // (make_plan rewrote the column fields of the words it staged)
     }

@@ -58,6 +58,7 @@ struct FormatOptions {
                                   //   memory costs more than the host packer saves (set of 20: prep + upload 1.38 s against 1.22 s)
     bool batch_layout = true;     // HISPMV_BATCH_LAYOUT=0: no second (long-group) layout for batch calls
     int batch_group_div = 4;      // HISPMV_BATCH_GROUP_DIV: the batch layout is planned for n_cus / this many workgroups (then / 3, / 2 when that plan does not keep its kind)
+    bool batch_plan_search = false;   // HISPMV_BATCH_PLAN_SEARCH=1: the batch layout's plan from all six planner configurations (as until the end of round 4) instead of the resident one alone
     int64_t batch_min_slices = 512;   // HISPMV_BATCH_MIN_SLICES: matrices with fewer slices keep their first layout (many short items: the filler at the end of the step kernel's queue)
     int batch_group_below = kBatchGroupBelow;     // HISPMV_BATCH_GROUP_BELOW (experiments): resident groups shorter than this get the batch layout
     bool decide_only = false;     // skip the device layouts the decision does not need (tests: the choice, not the bytes)

@@ -109,7 +109,7 @@ int ytile_floats_for(const SliceStream& st) {
     return std::min(kSliceElems, (max_rows + 63) & ~63);
 }
 
-LaunchPlan make_plan(SliceStream& st, int n_cus) {
+LaunchPlan make_plan(SliceStream& st, int n_cus, int only_cfg) {
     const int64_t n = st.n_slices;
     LaunchPlan best;
     best.ytile_floats = ytile_floats_for(st);
@@ -137,6 +137,7 @@ LaunchPlan make_plan(SliceStream& st, int n_cus) {
     for (const Cfg& c0 : cfgs) {
         ++cfg_index;
         if (force && (only < 0 || only != cfg_index)) continue;
+        if (only_cfg >= 0 && cfg_index != only_cfg) continue;
         // tiny matrices (< 4 MB of stream) are one latency chain long: staging a window adds two dependent
         // loads (fragment table, x) in front of it and buys nothing -- x is gathered through L2
         if (n < 512 && !force) break;
@@ -371,16 +372,24 @@ DeviceStream pack_device_stream(const SliceStream& st, const LaunchPlan& plan, b
 
 // The planned words of a part back to columns (make_plan rewrote the column field of staged groups to window indices).
 WordVec unplanned_words(const SliceStream& st, const LaunchPlan& plan) {
-    WordVec w = st.words;
+    // (the copy and the rewrite in ONE parallel pass over an uninitialised buffer: `WordVec w = st.words` walked 130 MB on one core for
+    // a matrix of TSOPF's size, twice with the stream copy of add_batch_layout -- 70 of the 185 ms a second layout cost)
+    WordVec w(st.words.size());
     const int64_t G = plan.group_slices, n = st.n_slices;
+    const int64_t n_groups = plan.groups.empty() ? (n + G - 1) / std::max<int64_t>(1, G) : (int64_t)plan.groups.size();
 #pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 16)
-    for (int64_t g = 0; g < (int64_t)plan.groups.size(); ++g) {
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t s0 = g * G, s1 = std::min<int64_t>(n, s0 + G);
+        const bool staged = g < (int64_t)plan.groups.size() && plan.groups[(size_t)g].frag_count > 0;
+        if (!staged) {                                                  // not staged: the words still hold columns
+            for (int64_t i = s0 * kSliceElems; i < s1 * kSliceElems; ++i) w[(size_t)i] = st.words[(size_t)i];
+            continue;
+        }
         const GroupDesc& gd = plan.groups[(size_t)g];
-        if (gd.frag_count <= 0) continue;                               // not staged: the words still hold columns
         const Frag* f0 = plan.frags.data() + gd.frag_begin;
         const Frag* f1 = f0 + gd.frag_count;
-        const int64_t s0 = g * G, s1 = std::min<int64_t>(n, s0 + G);
         for (int64_t i = s0 * kSliceElems; i < s1 * kSliceElems; ++i) {
+            w[(size_t)i] = st.words[(size_t)i];
             const uint32_t m = (uint32_t)(w[(size_t)i] >> 32);
             uint32_t col;
             if (m & kGlobalColBit) col = m & ~(kRowEndBit | kGlobalColBit);

@@ -48,7 +48,10 @@ struct LaunchPlan {
 
 // Chooses the plan for `st` on a device with n_cus compute units and REWRITES the column field of the
 // elements of every LDS-staged group in st.words to the element's index in that group's window.
-LaunchPlan make_plan(SliceStream& st, int n_cus);
+// only_cfg >= 0: evaluate that one configuration of the planner's table only (add_batch_layout: the resident configuration of the part's
+// first plan with longer groups -- five of six evaluations saved, 80 -> 15 ms for a matrix of TSOPF's size)
+LaunchPlan make_plan(SliceStream& st, int n_cus, int only_cfg = -1);
+constexpr int kPlanCfgResident512 = 2, kPlanCfgResident1024 = 5;
 
 // The words of a planned stream with COLUMNS in their meta field again (the inverse of make_plan's rewrite; hispmv_choose.cpp plans a
 // part a second time for its batch layout).
