@@ -52,6 +52,16 @@ def test_device_entry_points_check_their_arguments_before_touching_the_device():
     assert lib.hispmv_boundary_apply(None, None, None, None, 3, 2, None) == _lib.HISPMV_EINVAL
     assert lib.hispmv_boundary_apply(None, None, None, None, 0, 0, None) == _lib.HISPMV_EINVAL
     assert lib.hispmv_synchronize(None) == _lib.HISPMV_EINVAL
+    out = (C.c_int64 * 4)()
+    assert lib.hispmv_batch_call_info(None, out) == _lib.HISPMV_EINVAL                          # diagnostics of the batch entry point
+    assert lib.hispmv_batch_graph_stats(None, out) == _lib.HISPMV_EINVAL
+    # the host-only order of the step kernel's queue: bad arguments are refused, nothing is written
+    cls = (C.c_int32 * 2)(7, 7)
+    cost = (C.c_double * 1)(1.0)
+    assert lib.hispmv_prep_step_queue(cost, 1, cost, 1, 0, 0, cls, cls) == _lib.HISPMV_EINVAL   # no workgroups
+    assert lib.hispmv_prep_step_queue(cost, 1, cost, 1, 4, 9, cls, cls) == _lib.HISPMV_EINVAL   # unknown mode
+    assert lib.hispmv_prep_step_queue(None, 1, cost, 1, 4, 0, cls, cls) == _lib.HISPMV_EINVAL   # missing table
+    assert list(cls) == [7, 7]
 
 
 def test_facade_fails_loudly_without_a_device():
