@@ -10,7 +10,9 @@ CHILD (before touching any GPU), relays rank 0's JSON line and exits with the ch
 torch.distributed.run itself (RANK/WORLD_SIZE in the environment) it is one of the ranks.
 
 A "step" is one pass over the workload, every operand already resident in HBM:
-  set       (default) one SpMV per matrix of the set, ONE hispmv_spmv_device_batch call.  ~1.2 GB of packed stream per
+  set       (default) one SpMV per matrix of the set, ONE hispmv_spmv_device_batch call -- which the library issues as the step
+            kernel (one persistent workgroup per CU drawing the slice groups and tiles of all matrices from a queue) + one tail
+            launch; "batch_call" / "rank_step" of the JSON line say how the step just timed was issued.  ~1.2 GB of packed stream per
             step, far more than the 256 MiB Infinity Cache: every launch streams from HBM.  SuiteSparse files cannot be
             downloaded here; matrices/<name>/<name>.mtx is used when present, otherwise the seeded stand-in with the
             real matrix's rows and nnz (hispmv_amd/matrices.py).  The JSON line also carries the pessimistic stand-in
